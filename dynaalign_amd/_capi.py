@@ -1,0 +1,96 @@
+"""ctypes binding of libdynaalign_hip.so -- the C ABI declared in include/dynaalign.h.
+
+This module is the Python-side equivalent of the Rcpp glue in r_glue/: it only
+marshals arguments.  All compute happens in the HIP library; if the library (or
+a GPU) is missing, calls fail loudly -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libdynaalign_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dynaalign.h")
+
+DA_OK = 0
+DA_ERR_EMPTY_INPUT, DA_ERR_BAD_K, DA_ERR_BAD_NHASH, DA_ERR_BAD_MATRIX = 1, 2, 3, 4
+DA_ERR_BAD_RESIDUE_SEQ1, DA_ERR_BAD_RESIDUE_SEQ2, DA_ERR_NOMEM, DA_ERR_NO_DEVICE = 5, 6, 7, 8
+DA_ERR_HIP, DA_ERR_UNSUPPORTED, DA_ERR_BAD_ARG = 9, 10, 11
+DA_OUT_F64, DA_OUT_COMPACT = 0, 1
+
+_vp, _i64, _i32, _u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32
+
+# name -> (restype, argtypes).  Must list every symbol include/dynaalign.h declares
+# (tests/test_abi.py checks the two against each other).
+SIGNATURES = {
+    "da_last_error": (C.c_char_p, []),
+    "da_status_message": (C.c_char_p, [_i32]),
+    "da_abi_version": (_i32, []),
+    "da_device_count": (_i32, []),
+    "da_hash_family_seeds": (_i32, [_u32, _i32, _vp]),
+    "da_random_seed": (_u32, []),
+    "da_similarity_mh": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "da_minhash_signatures": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "da_mh_counts": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _i64, _vp]),
+    "da_similarity_nw": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _vp]),
+    "da_nw_pairs": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "da_sig_ld": (_i64, [_i32]),
+    "da_dev_minhash_signatures": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "da_dev_mh_compare": (_i32, [_vp, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "da_matrix_id": (_i32, [C.c_char_p]),
+    "da_dev_symmetrize": (_i32, [_vp, _i64, _i64, _i32, _vp]),
+    "da_dev_widen": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class DynaAlignError(RuntimeError):
+    """Raised for any non-zero status; .code is the da_status, str() the library's message
+    (for the reference's own error conditions: the reference's message text)."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+def header_symbols(path=HEADER_PATH):
+    """Function names declared in include/dynaalign.h."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(da_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load(path=None):
+    """dlopen the HIP library (once) and set prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("DYNAALIGN_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise DynaAlignError(
+            DA_ERR_NO_DEVICE,
+            "libdynaalign_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(dynaalign_amd has no CPU fallback)" % path)
+    try:  # if torch is around, let its bundled libamdhip64.so.7 be the one HIP runtime in the process
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != DA_OK:
+        raise DynaAlignError(rc, load().da_last_error().decode("latin-1"))
+
+
+def ptr(a):
+    """numpy array -> void* (None passes NULL)"""
+    return None if a is None else a.ctypes.data

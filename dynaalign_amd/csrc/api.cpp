@@ -1,0 +1,435 @@
+// api.cpp -- the C ABI of libdynaalign_hip.so (see include/dynaalign.h).
+//
+// Host-side marshalling only: argument validation with the reference's error
+// order and message texts, packing, H2D/D2H, and kernel launches.  There is
+// deliberately NO CPU implementation of the hot path in this library.
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <vector>
+
+#include "da_common.hpp"
+
+namespace da {
+
+const signed char *matrix_table_host(int id);
+const char *matrix_name_host(int id);
+int matrix_count_host();
+
+std::string &last_error_ref() {
+  static thread_local std::string msg;
+  return msg;
+}
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error_ref() = buf;
+  return code;
+}
+
+namespace {
+
+// RAII device buffer
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(e == hipErrorOutOfMemory ? DA_ERR_NOMEM : DA_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes,
+                  hipGetErrorString(e));
+    }
+    return DA_OK;
+  }
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+int require_device() {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0)
+    return fail(DA_ERR_NO_DEVICE,
+                "no usable HIP device (%s); libdynaalign_hip has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  return DA_OK;
+}
+
+// reference src/minHash.cpp:121-131, in that order
+int validate_mh(int64_t n, int k, int n_hash) {
+  if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
+  if (k <= 0) return fail(DA_ERR_BAD_K, "%s", da_status_message(DA_ERR_BAD_K));
+  if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
+  return DA_OK;
+}
+
+int64_t sig_ld_for(int n_hash) { return ((int64_t)n_hash + 31) / 32 * 32; }
+
+int check_offsets(const int64_t *offsets, int64_t n, int64_t *total, int64_t *max_len) {
+  if (!offsets) return fail(DA_ERR_BAD_ARG, "offsets is NULL");
+  int64_t mx = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t len = offsets[i + 1] - offsets[i];
+    if (len < 0) return fail(DA_ERR_BAD_ARG, "offsets must be non-decreasing (sequence %lld)", (long long)i);
+    mx = std::max(mx, len);
+  }
+  if (offsets[0] != 0) return fail(DA_ERR_BAD_ARG, "offsets[0] must be 0");
+  *total = offsets[n];
+  *max_len = mx;
+  return DA_OK;
+}
+
+// Upload the packed sequences (+ optionally seeds) to the current device.
+struct DeviceInput {
+  DevBuf res, off, seeds;
+  int upload(const uint8_t *residues, const int64_t *offsets, int64_t n, int64_t total,
+             const uint32_t *seedv, int n_hash) {
+    int rc;
+    if ((rc = res.alloc((size_t)total)) != DA_OK) return rc;
+    if ((rc = off.alloc((size_t)(n + 1) * sizeof(int64_t))) != DA_OK) return rc;
+    if (total) DA_HIP_TRY(hipMemcpy(res.p, residues, (size_t)total, hipMemcpyHostToDevice));
+    DA_HIP_TRY(hipMemcpy(off.p, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (seedv) {
+      if ((rc = seeds.alloc((size_t)n_hash * sizeof(uint32_t))) != DA_OK) return rc;
+      DA_HIP_TRY(hipMemcpy(seeds.p, seedv, (size_t)n_hash * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    return DA_OK;
+  }
+};
+
+// How many result rows to keep on the device at once (host-pointer paths).
+int64_t rows_per_block(int64_t n, size_t bytes_per_elem) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  size_t budget = free_b / 2;
+  if (const char *e = getenv("DYNAALIGN_BLOCK_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);
+  int64_t rows = (int64_t)(budget / ((size_t)n * bytes_per_elem));
+  rows = rows / 128 * 128;
+  if (rows < 128) rows = 128;
+  return std::min(rows, n);
+}
+
+}  // namespace
+}  // namespace da
+
+using namespace da;
+
+extern "C" {
+
+const char *da_last_error(void) { return last_error_ref().c_str(); }
+
+const char *da_status_message(int status) {
+  switch (status) {
+    case DA_ERR_EMPTY_INPUT: return "Input sequences vector cannot be empty";      // src/minHash.cpp:122
+    case DA_ERR_BAD_K: return "'k' must be a positive integer";                   // src/minHash.cpp:126
+    case DA_ERR_BAD_NHASH: return "Number of hash functions must be positive";     // src/minHash.cpp:130
+    case DA_ERR_BAD_MATRIX: return "Invalid substitution matrix name: %s";         // src/pairwiseSeqAlign.cpp:204
+    case DA_ERR_BAD_RESIDUE_SEQ1: return "Invalid amino acid in sequence1: %c";    // :242
+    case DA_ERR_BAD_RESIDUE_SEQ2: return "Invalid amino acid in sequence2: %c";    // :249
+    case DA_ERR_NOMEM: return "out of memory";
+    case DA_ERR_NO_DEVICE: return "no usable HIP device";
+    case DA_ERR_HIP: return "HIP runtime error";
+    case DA_ERR_UNSUPPORTED: return "unsupported by the gfx950 kernels";
+    case DA_ERR_BAD_ARG: return "bad argument";
+    default: return "";
+  }
+}
+
+int da_abi_version(void) { return DA_ABI_VERSION; }
+
+int da_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+
+// std::mt19937 restated (ISO C++ [rand.predef]); the reference draws the seeds
+// through uniform_int_distribution<uint32_t> over the full range, which returns
+// the raw engine output on libstdc++ (reference src/minHash.cpp:75-80).
+int da_hash_family_seeds(uint32_t seed, int n_hash, uint32_t *seeds_out) {
+  if (n_hash < 0 || (n_hash > 0 && !seeds_out)) return fail(DA_ERR_BAD_ARG, "bad n_hash / seeds_out");
+  uint32_t s[624];
+  s[0] = seed;
+  for (uint32_t i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + i;
+  int pos = 624;
+  for (int o = 0; o < n_hash; ++o) {
+    if (pos == 624) {
+      for (int i = 0; i < 624; ++i) {
+        const uint32_t y = (s[i] & 0x80000000u) | (s[(i + 1) % 624] & 0x7fffffffu);
+        s[i] = s[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      pos = 0;
+    }
+    uint32_t y = s[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    seeds_out[o] = y;
+  }
+  return DA_OK;
+}
+
+uint32_t da_random_seed(void) { return std::random_device{}(); }  // src/minHash.cpp:73
+
+int da_matrix_id(const char *matrix_name) {
+  if (matrix_name)
+    for (int i = 0; i < matrix_count_host(); ++i)
+      if (strcmp(matrix_name, matrix_name_host(i)) == 0) return i;
+  fail(DA_ERR_BAD_MATRIX, "Invalid substitution matrix name: %s", matrix_name ? matrix_name : "");
+  return -1;
+}
+
+// --------------------------------------------------------------- dev entry
+
+int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n,
+                              int64_t total_residues, int64_t max_len, int k, int n_hash,
+                              const uint32_t *d_seeds, uint32_t *d_sig, int64_t ld_sig, void *stream) {
+  (void)total_residues; (void)max_len;
+  int rc = validate_mh(n, k, n_hash);
+  if (rc != DA_OK) return rc;
+  if (!d_residues || !d_offsets || !d_seeds || !d_sig) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if (ld_sig < n_hash) return fail(DA_ERR_BAD_ARG, "ld_sig (%lld) < n_hash (%d)", (long long)ld_sig, n_hash);
+  return launch_minhash_signatures(d_residues, d_offsets, n, k, n_hash, d_seeds, d_sig, ld_sig,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int da_dev_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+                      int64_t row_begin, int64_t row_end, int symmetric, int kind, void *d_out,
+                      int64_t ld, void *stream) {
+  if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
+  if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
+  if (!d_sig || !d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(DA_ERR_BAD_ARG, "bad row range");
+  if (symmetric && (row_begin != 0 || row_end != n))
+    return fail(DA_ERR_BAD_ARG, "symmetric mode needs the full row range");
+  if (ld < n) return fail(DA_ERR_BAD_ARG, "ld (%lld) < n (%lld)", (long long)ld, (long long)n);
+  if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "bad output kind");
+  if (kind == DA_OUT_COMPACT && n_hash > 65535)
+    return fail(DA_ERR_UNSUPPORTED, "uint16 match counts need n_hash <= 65535 (got %d)", n_hash);
+  if ((ld_sig & 3) || (reinterpret_cast<uintptr_t>(d_sig) & 15) || ld_sig < n_hash)
+    return fail(DA_ERR_BAD_ARG, "signature matrix must be 16-byte aligned with ld_sig %% 4 == 0 and ld_sig >= n_hash");
+  return launch_mh_compare(d_sig, ld_sig, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
+                           static_cast<hipStream_t>(stream));
+}
+
+int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues, uint8_t *d_codes,
+                     int32_t *d_bad, void *stream) {
+  if (total_residues > 0 && (!d_residues || !d_codes || !d_bad)) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  return launch_nw_encode(d_residues, total_residues, d_codes, d_bad, static_cast<hipStream_t>(stream));
+}
+
+int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len,
+              int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
+              int symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score, int64_t ld_score,
+              void *stream) {
+  if (n <= 0) return DA_OK;
+  if (!d_codes || !d_offsets || !d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(DA_ERR_BAD_ARG, "bad row range");
+  if (symmetric && (row_begin != 0 || row_end != n))
+    return fail(DA_ERR_BAD_ARG, "symmetric mode needs the full row range");
+  if (ld < n || (d_score && ld_score < n)) return fail(DA_ERR_BAD_ARG, "leading dimension < n");
+  if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "bad output kind");
+  return launch_nw(d_codes, d_offsets, n, max_len, matrix_id, gap_open, gap_ext, row_begin, row_end,
+                   symmetric != 0, kind, d_out, ld, d_score, ld_score, static_cast<hipStream_t>(stream));
+}
+
+int da_dev_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, void *stream) {
+  if (!d_mat || ld < n) return fail(DA_ERR_BAD_ARG, "bad matrix / ld");
+  return launch_symmetrize(d_mat, n, ld, kind, static_cast<hipStream_t>(stream));
+}
+
+int da_dev_widen(const uint16_t *d_in, double *d_out, int64_t count, int is_nw, int n_hash, void *stream) {
+  if (count > 0 && (!d_in || !d_out)) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  return launch_widen(d_in, d_out, count, is_nw != 0, n_hash, static_cast<hipStream_t>(stream));
+}
+
+int64_t da_sig_ld(int n_hash) { return sig_ld_for(n_hash); }
+
+// -------------------------------------------------------------- host entry
+
+int da_minhash_signatures(const uint8_t *residues, const int64_t *offsets, int64_t n, int k,
+                          int n_hash, const uint32_t *seeds, uint32_t *sig_out) {
+  int rc = validate_mh(n, k, n_hash);
+  if (rc != DA_OK) return rc;
+  if (!residues || !seeds || !sig_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  int64_t total, max_len;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  if ((rc = require_device()) != DA_OK) return rc;
+  DeviceInput in;
+  if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
+  const int64_t ld = sig_ld_for(n_hash);
+  DevBuf sig;
+  if ((rc = sig.alloc((size_t)n * ld * sizeof(uint32_t))) != DA_OK) return rc;
+  rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), ld, nullptr);
+  if (rc != DA_OK) return rc;
+  DA_HIP_TRY(hipMemcpy2D(sig_out, (size_t)n_hash * 4, sig.p, (size_t)ld * 4, (size_t)n_hash * 4, (size_t)n,
+                         hipMemcpyDeviceToHost));
+  return DA_OK;
+}
+
+static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                          const uint32_t *seeds, int64_t row_begin, int64_t row_end, int kind, void *out) {
+  int rc = validate_mh(n, k, n_hash);
+  if (rc != DA_OK) return rc;
+  if (!residues || !seeds || !out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(DA_ERR_BAD_ARG, "bad row range");
+  if (kind == DA_OUT_COMPACT && n_hash > 65535)
+    return fail(DA_ERR_UNSUPPORTED, "uint16 match counts need n_hash <= 65535 (got %d)", n_hash);
+  int64_t total, max_len;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  if ((rc = require_device()) != DA_OK) return rc;
+  DeviceInput in;
+  if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
+  const int64_t lds = sig_ld_for(n_hash);
+  DevBuf sig;
+  if ((rc = sig.alloc((size_t)n * lds * sizeof(uint32_t))) != DA_OK) return rc;
+  rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, nullptr);
+  if (rc != DA_OK) return rc;
+  const size_t esz = kind == DA_OUT_F64 ? sizeof(double) : sizeof(uint16_t);
+  const int64_t rows_total = row_end - row_begin;
+  const int64_t blk = rows_per_block(n, esz);
+  const bool whole = (row_begin == 0 && row_end == n && blk >= n);
+  DevBuf dout;
+  if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * esz)) != DA_OK) return rc;
+  if (whole) {  // everything fits: compare only the upper triangle, store both halves
+    rc = launch_mh_compare(sig.as<uint32_t>(), lds, n, n_hash, 0, n, true, kind, dout.p, n, nullptr);
+    if (rc != DA_OK) return rc;
+    DA_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * (size_t)n * esz, hipMemcpyDeviceToHost));
+    return DA_OK;
+  }
+  for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
+    const int64_t r1 = std::min(row_end, r0 + blk);
+    rc = launch_mh_compare(sig.as<uint32_t>(), lds, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr);
+    if (rc != DA_OK) return rc;
+    DA_HIP_TRY(hipMemcpy(static_cast<char *>(out) + (size_t)(r0 - row_begin) * (size_t)n * esz, dout.p,
+                         (size_t)(r1 - r0) * (size_t)n * esz, hipMemcpyDeviceToHost));
+  }
+  return DA_OK;
+}
+
+int da_similarity_mh(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                     const uint32_t *seeds, double *out) {
+  return mh_host_common(residues, offsets, n, k, n_hash, seeds, 0, n > 0 ? n : 0, DA_OUT_F64, out);
+}
+
+int da_mh_counts(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                 const uint32_t *seeds, int64_t row_begin, int64_t row_end, uint16_t *counts_out) {
+  return mh_host_common(residues, offsets, n, k, n_hash, seeds, row_begin, row_end, DA_OUT_COMPACT, counts_out);
+}
+
+// Residue validation with the reference's laziness (src/pairwiseSeqAlign.cpp:238-250):
+// pairs are visited i ascending, j from i; inside a pair, sequence1[r] is checked at
+// the start of DP row r+1, and all of sequence2 is scanned during DP row 1.  A pair
+// with an empty sequence1 checks nothing.  Hence the first error raised is for the
+// pair (i0, jb): i0 = first non-empty sequence, jb = first sequence holding an
+// invalid byte (jb >= i0 necessarily).
+static int nw_validate(const uint8_t *residues, const int64_t *offsets, int64_t n) {
+  static const char order[] = "ARNDCQEGHILKMFPSTWYVBZX*";
+  auto valid = [&](uint8_t c) { return c != 0 && strchr(order, c) != nullptr; };
+  int64_t i0 = -1, jb = -1;
+  for (int64_t i = 0; i < n && (i0 < 0 || jb < 0); ++i) {
+    const int64_t b = offsets[i], e = offsets[i + 1];
+    if (i0 < 0 && e > b) i0 = i;
+    if (jb < 0)
+      for (int64_t p = b; p < e; ++p)
+        if (!valid(residues[p])) { jb = i; break; }
+  }
+  if (jb < 0) return DA_OK;
+  const uint8_t *s2 = residues + offsets[jb];
+  const int64_t n2 = offsets[jb + 1] - offsets[jb];
+  if (jb == i0 && !valid(s2[0]))
+    return fail(DA_ERR_BAD_RESIDUE_SEQ1, "Invalid amino acid in sequence1: %c", (char)s2[0]);
+  for (int64_t p = 0; p < n2; ++p)
+    if (!valid(s2[p])) return fail(DA_ERR_BAD_RESIDUE_SEQ2, "Invalid amino acid in sequence2: %c", (char)s2[p]);
+  return DA_OK;  // unreachable
+}
+
+static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                          const char *matrix_name, int gap_open, int gap_ext, int64_t row_begin,
+                          int64_t row_end, double *out_f64, int32_t *matches_out, int32_t *len_out,
+                          int32_t *score_out) {
+  const int mid = da_matrix_id(matrix_name);  // reference :338 -> :190-206, before anything else
+  if (mid < 0) return DA_ERR_BAD_MATRIX;
+  if (n <= 0) return DA_OK;                    // reference returns a 0x0 matrix
+  if (!residues) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(DA_ERR_BAD_ARG, "bad row range");
+  int64_t total, max_len;
+  int rc;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  if ((rc = nw_validate(residues, offsets, n)) != DA_OK) return rc;
+  if ((rc = require_device()) != DA_OK) return rc;
+  DeviceInput in;
+  if ((rc = in.upload(residues, offsets, n, total, nullptr, 0)) != DA_OK) return rc;
+  DevBuf codes, bad;
+  if ((rc = codes.alloc((size_t)total)) != DA_OK) return rc;
+  if ((rc = bad.alloc(sizeof(int32_t))) != DA_OK) return rc;
+  DA_HIP_TRY(hipMemset(bad.p, 0, sizeof(int32_t)));
+  if ((rc = launch_nw_encode(in.res.as<uint8_t>(), total, codes.as<uint8_t>(), bad.as<int32_t>(), nullptr)) != DA_OK)
+    return rc;
+
+  const int64_t rows_total = row_end - row_begin;
+  if (out_f64) {
+    const int64_t blk = rows_per_block(n, sizeof(double));
+    const bool whole = (row_begin == 0 && row_end == n && blk >= n);
+    DevBuf dout;
+    if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * sizeof(double))) != DA_OK) return rc;
+    for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
+      const int64_t r1 = std::min(row_end, r0 + blk);
+      rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, r0, r1,
+                     whole, DA_OUT_F64, dout.p, n, nullptr, 0, nullptr);
+      if (rc != DA_OK) return rc;
+      DA_HIP_TRY(hipMemcpy(out_f64 + (size_t)(r0 - row_begin) * (size_t)n, dout.p,
+                           (size_t)(r1 - r0) * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return DA_OK;
+  }
+  // integer outputs: compact (matches<<8|len) + score, widened on the host
+  const int64_t blk = rows_per_block(n, sizeof(uint16_t) + sizeof(int32_t));
+  DevBuf dpk, dsc;
+  const int64_t brow = std::min(blk, rows_total);
+  if ((rc = dpk.alloc((size_t)brow * (size_t)n * sizeof(uint16_t))) != DA_OK) return rc;
+  if (score_out && (rc = dsc.alloc((size_t)brow * (size_t)n * sizeof(int32_t))) != DA_OK) return rc;
+  std::vector<uint16_t> hpk((size_t)brow * (size_t)n);
+  for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
+    const int64_t r1 = std::min(row_end, r0 + blk);
+    const bool whole = (r0 == 0 && r1 == n);
+    rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, r0, r1, whole,
+                   DA_OUT_COMPACT, dpk.p, n, score_out ? dsc.as<int32_t>() : nullptr, n, nullptr);
+    if (rc != DA_OK) return rc;
+    const size_t cnt = (size_t)(r1 - r0) * (size_t)n, base = (size_t)(r0 - row_begin) * (size_t)n;
+    DA_HIP_TRY(hipMemcpy(hpk.data(), dpk.p, cnt * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < cnt; ++e) {
+      if (matches_out) matches_out[base + e] = hpk[e] >> 8;
+      if (len_out) len_out[base + e] = hpk[e] & 255;
+    }
+    if (score_out) DA_HIP_TRY(hipMemcpy(score_out + base, dsc.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return DA_OK;
+}
+
+int da_similarity_nw(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name,
+                     int gap_open, int gap_ext, double *out) {
+  if (n > 0 && !out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  return nw_host_common(residues, offsets, n, matrix_name, gap_open, gap_ext, 0, n > 0 ? n : 0, out, nullptr,
+                        nullptr, nullptr);
+}
+
+int da_nw_pairs(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name,
+                int gap_open, int gap_ext, int64_t row_begin, int64_t row_end, int32_t *matches_out,
+                int32_t *len_out, int32_t *score_out) {
+  return nw_host_common(residues, offsets, n, matrix_name, gap_open, gap_ext, row_begin, row_end, nullptr,
+                        matches_out, len_out, score_out);
+}
+
+}  // extern "C"

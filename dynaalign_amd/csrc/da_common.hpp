@@ -1,0 +1,51 @@
+// da_common.hpp -- shared host-side plumbing for libdynaalign_hip.so
+// (error channel, HIP call checking, launch-geometry helpers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/dynaalign.h"
+
+namespace da {
+
+// thread-local message behind da_last_error()
+std::string &last_error_ref();
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define DA_HIP_TRY(expr)                                                              \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return ::da::fail(_e == hipErrorNoDevice || _e == hipErrorInvalidDevice         \
+                            ? DA_ERR_NO_DEVICE                                        \
+                            : DA_ERR_HIP,                                             \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                        __FILE__, __LINE__);                                          \
+  } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Kernel launchers implemented in the .hip translation units.  All are
+// asynchronous on `stream`; argument checking is done by the C-ABI layer.
+int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n,
+                              int k, int n_hash, const uint32_t *d_seeds, uint32_t *d_sig,
+                              int64_t ld_sig, hipStream_t stream);
+int launch_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+                      int64_t row_begin, int64_t row_end, bool symmetric, int kind,
+                      void *d_out, int64_t ld, hipStream_t stream);
+int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,
+                     hipStream_t stream);
+int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,
+              int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
+              bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
+              int64_t ld_score, hipStream_t stream);
+int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream);
+int launch_widen(const uint16_t *d_in, double *d_out, int64_t count, bool is_nw, int n_hash,
+                 hipStream_t stream);
+
+}  // namespace da

@@ -1,0 +1,470 @@
+// minhash_kernels.hip -- gfx950 kernels for the similarityMH hot path.
+//
+//   K1  k_minhash_signatures : k-shingle MurmurHash3 + per-sequence running min
+//                              (reference src/minHash.cpp:140-157, hash :21-64)
+//   K2  k_mh_compare         : all-pairs signature equality count + divide
+//                              (reference src/minHash.cpp:160-178)
+//
+// Written for CDNA4 only: 64-wide wavefronts, 160 KiB LDS, 8 XCDs.  Integer
+// work; no MFMA (an equality count is not a contraction).
+#include "da_common.hpp"
+
+namespace da {
+namespace {
+
+// ---------------------------------------------------------------- murmur3 --
+// MurmurHash3_x86_32 split so that the seed-independent part of every 4-byte
+// block ("scramble") is computed once per window position and shared by all
+// n_hash seeds.  Reference: src/minHash.cpp:22-27 (constants), :34-41 (body),
+// :43-54 (tail), :56-61 (finaliser).
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int r) {
+  return __builtin_rotateleft32(v, r);
+}
+__device__ __forceinline__ uint32_t mm3_scramble(uint32_t w) {
+  w *= 0xcc9e2d51u;
+  w = rotl32(w, 15);
+  w *= 0x1b873593u;
+  return w;
+}
+__device__ __forceinline__ uint32_t mm3_mix(uint32_t h, uint32_t kk) {
+  h ^= kk;
+  return rotl32(h, 13) * 5u + 0xe6546b64u;
+}
+__device__ __forceinline__ uint32_t mm3_final(uint32_t h, uint32_t len) {
+  h ^= len;
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+
+constexpr int K1_THREADS = 256;
+constexpr int K1_CHUNK = 1024;  // window positions staged per pass
+
+// One workgroup per sequence.  Pass structure for a chunk of window positions
+// [c0, c0+CH):
+//   1. all threads cooperatively read the residue bytes the chunk needs
+//      (coalesced byte reads of the packed buffer) and write, per byte
+//      position q, the scrambled 4-byte block starting at q (KK[q]) and the
+//      scrambled (k&3)-byte tail starting at q (TT[q]) into LDS;
+//   2. thread t owns hash functions h = t, t+256, ...: for each it walks the
+//      chunk's windows, rebuilding murmur3(window, seed_h) from KK/TT (LDS
+//      broadcast reads: every lane reads the same address) and keeps the
+//      running min in a register -- no cross-lane reduction is needed because
+//      lanes are spread over hash functions, not over windows.
+// Window p of a k-byte shingle uses blocks KK[p], KK[p+4], ... (k/4 of them)
+// and tail TT[p + 4*(k/4)].
+template <bool K_IS_4>
+__global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
+    const uint8_t *__restrict__ residues, const int64_t *__restrict__ offsets, int k, int n_hash,
+    const uint32_t *__restrict__ seeds, uint32_t *__restrict__ sig, int64_t ld_sig) {
+  extern __shared__ uint32_t lds_k1[];
+  const int64_t seq = blockIdx.x;
+  const int64_t beg = offsets[seq];
+  const int64_t len = offsets[seq + 1] - beg;
+  const int64_t nwin = (len >= k) ? (len - k + 1) : 0;  // src/minHash.cpp:98-103
+  const int nblk = k >> 2, rem = k & 3;
+  const int span = K1_CHUNK + k;  // byte positions whose KK/TT a chunk may touch
+  uint32_t *KK = lds_k1;
+  uint32_t *TT = lds_k1 + span;
+  uint32_t *row = sig + seq * ld_sig;
+  const uint8_t *s = residues + beg;
+
+  if (nwin == 0) {  // identity of min: UINT32_MAX (src/minHash.cpp:140)
+    for (int h = threadIdx.x; h < n_hash; h += K1_THREADS) row[h] = 0xffffffffu;
+    return;
+  }
+  for (int64_t c0 = 0; c0 < nwin; c0 += K1_CHUNK) {
+    const int cw = (int)((nwin - c0 < K1_CHUNK) ? (nwin - c0) : K1_CHUNK);
+    const int need = cw + k - 1;  // byte positions c0 .. c0+need-1 are inside the sequence
+    __syncthreads();
+    for (int q = threadIdx.x; q < need; q += K1_THREADS) {
+      const int64_t g = c0 + q;
+      uint32_t b0 = s[g];
+      uint32_t b1 = (g + 1 < len) ? s[g + 1] : 0u;
+      uint32_t b2 = (g + 2 < len) ? s[g + 2] : 0u;
+      uint32_t b3 = (g + 3 < len) ? s[g + 3] : 0u;
+      KK[q] = mm3_scramble(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+      if (!K_IS_4) {
+        uint32_t t = b0;
+        if (rem >= 2) t |= b1 << 8;
+        if (rem == 3) t |= b2 << 16;
+        TT[q] = mm3_scramble(t);
+      }
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < n_hash; h += K1_THREADS) {
+      const uint32_t seed = seeds[h];
+      uint32_t best = (c0 == 0) ? 0xffffffffu : row[h];
+      if (K_IS_4) {
+#pragma unroll 4
+        for (int p = 0; p < cw; ++p) {
+          uint32_t v = mm3_final(mm3_mix(seed, KK[p]), 4u);
+          best = v < best ? v : best;
+        }
+      } else {
+        for (int p = 0; p < cw; ++p) {
+          uint32_t hh = seed;
+          for (int b = 0; b < nblk; ++b) hh = mm3_mix(hh, KK[p + 4 * b]);
+          if (rem) hh ^= TT[p + 4 * nblk];
+          uint32_t v = mm3_final(hh, (uint32_t)k);
+          best = v < best ? v : best;
+        }
+      }
+      row[h] = best;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- compare --
+// Pair-space tile of 128 x 128 per 256-thread workgroup; each lane keeps an
+// 8 x 8 block of match counters in registers (64 VGPRs).  Signature slices of
+// HC = 32 hash functions are staged through LDS; per 4 hash functions a lane
+// issues 8 + 8 ds_read_b128 and 256 compare+add pairs, so the kernel is bound
+// by integer VALU issue (2 lane-ops per compare), not by LDS or HBM.
+constexpr int K2_TILE = 128;
+constexpr int K2_HC = 32;            // hash functions per LDS stage
+constexpr int K2_SEGS = K2_HC / 4;   // 16-byte segments per row per stage
+constexpr int K2_BAND = 8;           // tile rows per L2-resident band
+constexpr int K2_THREADS = 256;
+
+// Rows/cols owned by lane coordinate t (0..15):  32*g + 2*t + e, g=0..3, e=0..1.
+// LDS slot of tile row r:  ((r>>5)*2 + (r&1))*16 + ((r&31)>>1)  -- makes the
+// 16 lanes of a ds_read_b128 group hit consecutive slots.
+__device__ __forceinline__ int k2_slot(int r) { return (((r >> 5) * 2 + (r & 1)) << 4) + ((r & 31) >> 1); }
+// 16-byte unit index inside one operand buffer; XOR swizzle spreads the 8
+// segments of a slot over banks so both the staging writes (8 lanes = one
+// slot, 8 segments) and the compute reads (<= 8 consecutive slots, one
+// segment) are conflict-free.
+__device__ __forceinline__ int k2_unit(int slot, int seg) { return slot * K2_SEGS + (seg ^ (slot & 7)); }
+
+struct TileId { int ti, tj; bool valid; };
+
+// Enumeration of pair-space tiles.  Tile rows are grouped into bands of
+// K2_BAND; inside a band tiles are visited column-major, so ~64 consecutive
+// tile ids share 8 a-tiles (kept in the XCD's L2 for the whole band) and 8
+// b-tiles.  Consecutive ids go to one XCD (the caller's blockIdx remap).
+//   symmetric: only tiles with tj >= ti.   T = tiles per side (columns),
+//   rect     : tile rows [0,TR) x tile cols [0,T).
+__device__ __forceinline__ TileId decode_tile(int64_t L, int TR, int T, bool symmetric) {
+  TileId o{0, 0, true};
+  const int S = K2_BAND;
+  if (!symmetric) {
+    const int64_t per_band = (int64_t)S * T;
+    int B = (int)(L / per_band);
+    int64_t l = L - (int64_t)B * per_band;
+    int r0 = B * S;
+    int h = (TR - r0 < S) ? (TR - r0) : S;
+    if (h <= 0) { o.valid = false; return o; }
+    o.tj = (int)(l / h);
+    o.ti = r0 + (int)(l - (int64_t)o.tj * h);
+    o.valid = o.tj < T;
+    return o;
+  }
+  // full bands: count(B) = c0 - S*S*B, c0 = S(S+1)/2 + (T-S)*S ; prefix(B) = B*c0 - S*S*B(B-1)/2
+  const int nfull = T / S;  // bands with S rows
+  const int64_t c0 = (int64_t)S * (S + 1) / 2 + (int64_t)(T - S) * S;
+  auto prefix = [&](int64_t B) { return B * c0 - (int64_t)S * S * (B * (B - 1) / 2); };
+  int64_t B;
+  if (nfull > 0 && L < prefix(nfull)) {
+    // solve prefix(B) <= L: (S*S/2) B^2 - (c0 + S*S/2) B + L >= 0
+    const double a = 0.5 * S * S, b = (double)c0 + a;
+    double disc = b * b - 4.0 * a * (double)L;
+    B = (int64_t)((b - sqrt(disc > 0 ? disc : 0)) / (2.0 * a));
+    if (B < 0) B = 0;
+    if (B > nfull - 1) B = nfull - 1;
+    while (B > 0 && prefix(B) > L) --B;
+    while (B + 1 <= nfull - 1 && prefix(B + 1) <= L) ++B;
+  } else {
+    B = nfull;  // the partial last band (or invalid)
+  }
+  const int r0 = (int)B * S;
+  const int h = (T - r0 < S) ? (T - r0) : S;
+  if (h <= 0) { o.valid = false; return o; }
+  int64_t l = L - prefix(B < nfull ? B : nfull);
+  const int64_t tri = (int64_t)h * (h + 1) / 2;
+  if (l < tri) {  // the diagonal super-tile: column q holds q+1 tiles
+    int q = 0;
+    while ((int64_t)(q + 1) * (q + 2) / 2 <= l) ++q;
+    o.tj = r0 + q;
+    o.ti = r0 + (int)(l - (int64_t)q * (q + 1) / 2);
+  } else {
+    l -= tri;
+    int64_t cq = l / h;
+    o.tj = r0 + h + (int)cq;
+    o.ti = r0 + (int)(l - cq * h);
+  }
+  o.valid = o.tj < T;
+  return o;
+}
+
+__host__ __device__ inline int64_t count_tiles(int TR, int T, bool symmetric) {
+  if (!symmetric) return (int64_t)TR * T;
+  return (int64_t)T * (T + 1) / 2;
+}
+
+template <bool SYM, bool F64>
+__global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
+    const uint32_t *__restrict__ sig, int64_t ld_sig, int64_t n, int n_hash, int64_t row_begin,
+    int64_t row_end, void *__restrict__ out_v, int64_t ld, int64_t ntiles, int64_t per_xcd) {
+  __shared__ __attribute__((aligned(16))) uint4 lds_ab[2 * K2_TILE * K2_SEGS];  // 32 KiB: a-rows then b-rows
+
+  // ---- which tile: blocks b and b+8 share an XCD, so give XCD x the
+  // contiguous id range [x*per_xcd, (x+1)*per_xcd) (speed only).
+  const int64_t bid = blockIdx.x;
+  const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
+  if ((bid >> 3) >= per_xcd || L >= ntiles) return;
+  const int T = (int)((n + K2_TILE - 1) / K2_TILE);
+  const int TR = (int)((row_end - row_begin + K2_TILE - 1) / K2_TILE);
+  const TileId tid2 = decode_tile(L, TR, T, SYM);
+  if (!tid2.valid) return;
+  const int64_t I0 = row_begin + (int64_t)tid2.ti * K2_TILE;  // global row of tile row 0
+  const int64_t J0 = (int64_t)tid2.tj * K2_TILE;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int tx = ((wave & 1) << 3) + (lane & 7);   // column coordinate 0..15
+  const int ty = ((wave >> 1) << 3) + (lane >> 3); // row coordinate 0..15
+
+  // ---- staging assignment: 8 lanes fetch one signature row slice (8 x 16 B
+  // = 128 B contiguous); 256 threads cover 32 rows per pass, 8 passes cover
+  // the 128 a-rows + 128 b-rows.
+  const int st_seg = tid & 7;
+  const int st_row = tid >> 3;  // 0..31
+  uint4 stage[8];
+  auto fetch = [&](int h0) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int r = st_row + 32 * (p & 3);           // tile row/col index 0..127
+      const bool is_b = p >= 4;
+      const int64_t g = (is_b ? J0 : I0) + r;        // global sequence index
+      const int h = h0 + st_seg * 4;
+      const uint32_t pad = is_b ? 0xffffffffu : 0u;  // a-pad != b-pad: padding never matches
+      uint4 v = make_uint4(pad, pad, pad, pad);
+      if (g < n && h < n_hash) {  // rows are 16-byte aligned and ld_sig % 4 == 0: the vector load stays inside the row
+        v = *reinterpret_cast<const uint4 *>(sig + g * ld_sig + h);
+        if (h + 1 >= n_hash) v.y = pad;
+        if (h + 2 >= n_hash) v.z = pad;
+        if (h + 3 >= n_hash) v.w = pad;
+      }
+      stage[p] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int r = st_row + 32 * (p & 3);
+      const int base = (p >= 4) ? K2_TILE * K2_SEGS : 0;
+      lds_ab[base + k2_unit(k2_slot(r), st_seg)] = stage[p];
+    }
+  };
+
+  uint32_t acc[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[r][c] = 0;
+
+  const int nchunk = (n_hash + K2_HC - 1) / K2_HC;
+  fetch(0);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    __syncthreads();  // previous chunk's reads are done
+    commit();
+    __syncthreads();
+    if (ch + 1 < nchunk) fetch((ch + 1) * K2_HC);  // global loads fly under the compare loop
+#pragma unroll 1
+    for (int seg = 0; seg < K2_SEGS; ++seg) {
+      uint4 a[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) a[r] = lds_ab[k2_unit(r * 16 + ty, seg)];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint4 b = lds_ab[K2_TILE * K2_SEGS + k2_unit(c * 16 + tx, seg)];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          acc[r][c] += (a[r].x == b.x);
+          acc[r][c] += (a[r].y == b.y);
+          acc[r][c] += (a[r].z == b.z);
+          acc[r][c] += (a[r].w == b.w);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue.  count -> double through a table built with the same
+  // IEEE divide the reference does ((double)matches / n_hash,
+  // src/minHash.cpp:174); the staging LDS is free now and holds the table.
+  double *ratio = reinterpret_cast<double *>(lds_ab);
+  const bool use_table = F64 && (n_hash + 1) <= (int)(sizeof(lds_ab) / (sizeof(double)));
+  if (F64) {
+    __syncthreads();
+    if (use_table)
+      for (int c = tid; c <= n_hash; c += K2_THREADS) ratio[c] = (double)c / (double)n_hash;
+    __syncthreads();
+  }
+  auto widen = [&](uint32_t c) -> double {
+    return use_table ? ratio[c] : (double)c / (double)n_hash;
+  };
+
+  // lane's rows: 32*g + 2*ty + e  <-> acc index r = 2*g + e ; cols likewise.
+  if (F64) {
+    double *out = reinterpret_cast<double *>(out_v);
+    const bool vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
+      if (gi >= row_end || gi >= n) continue;
+      double *orow = out + (gi - row_begin) * ld;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t gj = J0 + 32 * g + 2 * tx;
+        const double v0 = widen(acc[r][2 * g]), v1 = widen(acc[r][2 * g + 1]);
+        if (vec_ok && gj + 1 < n) {
+          *reinterpret_cast<double2 *>(orow + gj) = make_double2(v0, v1);
+        } else {
+          if (gj < n) orow[gj] = v0;
+          if (gj + 1 < n) orow[gj + 1] = v1;
+        }
+      }
+    }
+    if (SYM && tid2.ti != tid2.tj) {  // mirrored store (src/minHash.cpp:176)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int64_t gj = J0 + 32 * (c >> 1) + 2 * tx + (c & 1);
+        if (gj >= n) continue;
+        double *orow = out + gj * ld;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t gi = I0 + 32 * g + 2 * ty;
+          const double v0 = widen(acc[2 * g][c]), v1 = widen(acc[2 * g + 1][c]);
+          if (vec_ok && gi + 1 < n) {
+            *reinterpret_cast<double2 *>(orow + gi) = make_double2(v0, v1);
+          } else {
+            if (gi < n) orow[gi] = v0;
+            if (gi + 1 < n) orow[gi + 1] = v1;
+          }
+        }
+      }
+    }
+  } else {
+    uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
+      if (gi >= row_end || gi >= n) continue;
+      uint16_t *orow = out + (gi - row_begin) * ld;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t gj = J0 + 32 * g + 2 * tx;
+        if (gj < n) orow[gj] = (uint16_t)acc[r][2 * g];
+        if (gj + 1 < n) orow[gj + 1] = (uint16_t)acc[r][2 * g + 1];
+      }
+    }
+    if (SYM && tid2.ti != tid2.tj) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int64_t gj = J0 + 32 * (c >> 1) + 2 * tx + (c & 1);
+        if (gj >= n) continue;
+        uint16_t *orow = out + gj * ld;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t gi = I0 + 32 * g + 2 * ty;
+          if (gi < n) orow[gi] = (uint16_t)acc[2 * g][c];
+          if (gi + 1 < n) orow[gi + 1] = (uint16_t)acc[2 * g + 1][c];
+        }
+      }
+    }
+  }
+}
+
+// Lower triangle <- upper triangle (after a gather of upper-triangular rows).
+template <typename T>
+__global__ __launch_bounds__(256) void k_symmetrize(T *__restrict__ m, int64_t n, int64_t ld) {
+  __shared__ T tile[32][33];
+  const int64_t bi = blockIdx.y, bj = blockIdx.x;  // tile (bi,bj) of the UPPER part is read
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < n && j < n) tile[r][tx] = m[i * ld + j];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t j = bj * 32 + r, i = bi * 32 + tx;  // write m[j][i] = upper(i,j)
+    if (i < n && j < n && j > i) m[j * ld + i] = tile[tx][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_widen(const uint16_t *__restrict__ in, double *__restrict__ out,
+                                               int64_t count, int is_nw, int n_hash) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const uint32_t v = in[i];
+    out[i] = is_nw ? (double)(v >> 8) / (double)(v & 255u) : (double)v / (double)n_hash;
+  }
+}
+
+}  // namespace
+
+int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n, int k,
+                              int n_hash, const uint32_t *d_seeds, uint32_t *d_sig,
+                              int64_t ld_sig, hipStream_t stream) {
+  if (n <= 0) return DA_OK;
+  if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "more than 2^31-1 sequences");
+  const size_t lds = 2 * (size_t)(K1_CHUNK + k) * sizeof(uint32_t);
+  if (lds > 64 * 1024) return fail(DA_ERR_UNSUPPORTED, "k = %d is larger than the signature kernel supports (k <= 7168)", k);
+  dim3 grid((unsigned)n), block(K1_THREADS);
+  if (k == 4)
+    hipLaunchKernelGGL(k_minhash_signatures<true>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig);
+  else
+    hipLaunchKernelGGL(k_minhash_signatures<false>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+int launch_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+                      int64_t row_begin, int64_t row_end, bool symmetric, int kind,
+                      void *d_out, int64_t ld, hipStream_t stream) {
+  if (row_end <= row_begin) return DA_OK;
+  const int T = (int)ceil_div(n, K2_TILE);
+  const int TR = (int)ceil_div(row_end - row_begin, K2_TILE);
+  const int64_t ntiles = count_tiles(TR, T, symmetric);
+  const int64_t per_xcd = ceil_div(ntiles, 8);
+  const int64_t nblocks = per_xcd * 8;
+  if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
+  dim3 grid((unsigned)nblocks), block(K2_THREADS);
+#define DA_K2(SYM, F64)                                                                          \
+  hipLaunchKernelGGL((k_mh_compare<SYM, F64>), grid, block, 0, stream, d_sig, ld_sig, n, n_hash, \
+                     row_begin, row_end, d_out, ld, ntiles, per_xcd)
+  if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true); else DA_K2(true, false); }
+  else           { if (kind == DA_OUT_F64) DA_K2(false, true); else DA_K2(false, false); }
+#undef DA_K2
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream) {
+  if (n <= 1) return DA_OK;
+  const unsigned t = (unsigned)ceil_div(n, 32);
+  dim3 grid(t, t), block(256);
+  if (kind == DA_OUT_F64)
+    hipLaunchKernelGGL(k_symmetrize<double>, grid, block, 0, stream, (double *)d_mat, n, ld);
+  else
+    hipLaunchKernelGGL(k_symmetrize<uint16_t>, grid, block, 0, stream, (uint16_t *)d_mat, n, ld);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+int launch_widen(const uint16_t *d_in, double *d_out, int64_t count, bool is_nw, int n_hash,
+                 hipStream_t stream) {
+  if (count <= 0) return DA_OK;
+  int64_t blocks = ceil_div(count, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_widen, dim3((unsigned)blocks), dim3(256), 0, stream, d_in, d_out, count, is_nw ? 1 : 0, n_hash);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+}  // namespace da

@@ -1,0 +1,310 @@
+// nw_kernels.hip -- gfx950 kernels for the similarityNW hot path.
+//
+//   K0  k_nw_encode : residue byte -> BLOSUM row index 0..23, flag anything
+//                     else (reference src/pairwiseSeqAlign.cpp:15-21, :240-250)
+//   K3  k_nw_short  : all-pairs affine-gap global alignment identity for
+//                     peptides up to NMAX residues (reference :209-313, driver
+//                     :331-365)
+//
+// K3 design (CDNA4, integer VALU; no MFMA -- a DP recurrence is not a
+// contraction):
+//   * one LANE per pair: a wavefront owns one row i of the pair space at a
+//     time and 64 consecutive columns j, so sequence1 = seq[i] is
+//     wave-uniform and sequence2 = seq[j] is lane-private.  The whole
+//     (m+1) x (n+1) DP of a pair lives in the lane's registers as one
+//     rolling row (M-goe, Ix, packed matches/len per column); there is no
+//     cross-lane traffic and every lane is busy on every step.
+//   * the traceback (reference :284-308) is replaced by carrying
+//     (matches, length) forward along the chosen predecessor -- SURVEY A.2,
+//     identical by construction because the reference's traceback reads only
+//     the move chosen at fill time.
+//   * scores come from a 24x24 table staged in LDS as {score + gapOpen + gapExt,
+//     1 + (a==b)<<16}: one conflict-free ds_read_b64 per cell (all lanes of a
+//     wave read inside one 192-byte table row).
+//   * only pairs with i <= j are evaluated, as calc(seq[i], seq[j])
+//     (reference :340-346; the function is not symmetric); the
+//     mirrored element is stored from the same lane (:349-350).
+#include <climits>
+
+#include "da_common.hpp"
+
+namespace da {
+namespace {
+
+#include "blosum_data.inc"
+
+struct ScoreTable { signed char s[576]; };  // passed by value in the kernarg segment
+
+// residue byte -> index (reference src/pairwiseSeqAlign.cpp:15-21)
+__device__ __forceinline__ int aa_index(uint32_t c) {
+  switch (c) {
+    case 'A': return 0;  case 'R': return 1;  case 'N': return 2;  case 'D': return 3;
+    case 'C': return 4;  case 'Q': return 5;  case 'E': return 6;  case 'G': return 7;
+    case 'H': return 8;  case 'I': return 9;  case 'L': return 10; case 'K': return 11;
+    case 'M': return 12; case 'F': return 13; case 'P': return 14; case 'S': return 15;
+    case 'T': return 16; case 'W': return 17; case 'Y': return 18; case 'V': return 19;
+    case 'B': return 20; case 'Z': return 21; case 'X': return 22; case '*': return 23;
+    default: return -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nw_encode(const uint8_t *__restrict__ res, int64_t total,
+                                                   uint8_t *__restrict__ codes, int32_t *__restrict__ bad) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+    const int ix = aa_index(res[p]);
+    codes[p] = (uint8_t)(ix < 0 ? 0 : ix);
+    if (ix < 0) {
+      const int64_t q = p < (int64_t)INT_MAX - 1 ? p : (int64_t)INT_MAX - 1;
+      atomicMax(bad, (int32_t)(INT_MAX - q));  // smallest position wins; 0 = all valid
+    }
+  }
+}
+
+constexpr int K3_THREADS = 256;
+constexpr int K3_ROWS_PER_WAVE = 16;
+constexpr int K3_TILE = 64;  // 4 waves x 16 rows, 64 columns
+
+struct Cell { int32_t s_goe; uint32_t inc; };  // LDS table entry (8 bytes)
+
+// One DP row for a lane: columns 1..NMAX, left to right.
+//   MG[c] : M[r-1][c] - (go+ge) on entry, M[r][c] - (go+ge) on exit  (c = 0..NMAX-1 <-> column c+1)
+//   X[c]  : Ix[r-1][c]  ->  Ix[r][c]
+//   P[c]  : (matches<<16 | len) of cell (r-1,c) -> (r,c)
+// FIRST: row 1, where M[0][c] = Ix[0][c] = NEG (reference :230-235), so
+// Ix[1][c] = max(NEG-goe, NEG-ge) for every c while the diagonal term still
+// sees max(M,Ix,Iy)[0][c-1] = Iy[0][c-1] (kept in MG by the initialisation).
+template <int NMAX, bool FIRST>
+__device__ __forceinline__ void nw_row(int32_t (&MG)[NMAX], int32_t (&X)[NMAX], uint32_t (&P)[NMAX],
+                                       const uint32_t (&boff)[NMAX], const char *tab_row,
+                                       int32_t mg_diag0, uint32_t p_diag0, uint32_t p_left0,
+                                       int32_t mg_left0, int32_t y_left0, int32_t ge, int32_t goe,
+                                       int32_t ix_first) {
+  int32_t mgd = mg_diag0;   // (max(M,Ix,Iy)[r-1][c-1]) - goe
+  uint32_t pd = p_diag0;
+  int32_t mgl = mg_left0;   // M[r][c-1] - goe
+  int32_t yl = y_left0;     // Iy[r][c-1]
+  uint32_t pl = p_left0;
+#pragma unroll
+  for (int c = 0; c < NMAX; ++c) {
+    const Cell e = *reinterpret_cast<const Cell *>(tab_row + boff[c]);
+    const int32_t ix = FIRST ? ix_first : max(MG[c], X[c] - ge);          // reference :255-257
+    const int32_t iy = max(mgl, yl - ge);                                   // :260-262
+    const int32_t d = mgd + e.s_goe;                                        // :265-268
+    const int32_t gap = max(ix, iy);
+    const bool take_d = d >= gap;                                           // :271
+    const bool up_over_left = ix >= iy;                                     // :273
+    const int32_t m = max(d, gap);                                          // :272-278 (M overwrite)
+    const uint32_t p_gap = (up_over_left ? P[c] : pl) + 1u;
+    const uint32_t p_new = take_d ? pd + e.inc : p_gap;
+    mgd = MG[c];
+    pd = P[c];
+    mgl = m - goe;
+    yl = iy;
+    pl = p_new;
+    MG[c] = mgl;
+    X[c] = ix;
+    P[c] = p_new;
+  }
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(K3_THREADS) void k_nw_short(
+    const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
+    ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
+    int f64_out, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
+    int64_t ld_score, int64_t ntiles, int T) {
+  __shared__ __attribute__((aligned(16))) Cell tab[24 * 24];
+  __shared__ uint8_t rowcodes[K3_TILE][NMAX];
+  __shared__ int32_t rowlen[K3_TILE];
+
+  // ---- tile decode (upper-triangular 64x64 tiles of the pair space)
+  const int64_t L = blockIdx.x;
+  if (L >= ntiles) return;
+  int ti, tj;
+  bool allow_direct = true, allow_mirror = true;
+  if (symmetric) {
+    // row-major over the upper triangle: row t holds T - t tiles
+    const double Td = (double)T;
+    int64_t t = (int64_t)(Td + 0.5 - sqrt((Td + 0.5) * (Td + 0.5) - 2.0 * (double)L));
+    if (t < 0) t = 0;
+    if (t > T - 1) t = T - 1;
+    auto start = [&](int64_t r) { return r * T - r * (r - 1) / 2; };
+    while (t > 0 && start(t) > L) --t;
+    while (t + 1 <= T - 1 && start(t + 1) <= L) ++t;
+    ti = (int)t;
+    tj = (int)(t + (L - start(t)));
+  } else {
+    // row-block request: tile row rt (inside the block) x every tile column tc.
+    // tc >= rt is the upper tile itself (direct store); tc < rt is served by
+    // the upper tile (tc, rt) through its mirrored store, so each element of
+    // the block is produced exactly once.
+    const int rt = (int)(row_begin / K3_TILE) + (int)(L / T);
+    const int tc = (int)(L % T);
+    ti = tc >= rt ? rt : tc;
+    tj = tc >= rt ? tc : rt;
+    allow_direct = tc >= rt;
+    allow_mirror = tc <= rt;
+  }
+  const int64_t I0 = (int64_t)ti * K3_TILE, J0 = (int64_t)tj * K3_TILE;
+  const int32_t goe = go + ge;
+  const int32_t NEG = INT_MIN / 2;
+
+  // ---- stage the score table and this tile's 64 row sequences in LDS
+  for (int e = threadIdx.x; e < 576; e += K3_THREADS) {
+    const int a = e / 24, b = e - a * 24;
+    tab[e].s_goe = (int32_t)table.s[e] + goe;
+    tab[e].inc = 1u + ((a == b) ? 0x10000u : 0u);  // equal index <=> equal residue byte (:291-293)
+  }
+  for (int r = threadIdx.x >> 2; r < K3_TILE; r += K3_THREADS / 4) {
+    const int64_t i = I0 + r;
+    const int64_t b = i < n ? offsets[i] : 0;
+    const int32_t len = i < n ? (int32_t)(offsets[i + 1] - b) : 0;
+    if ((threadIdx.x & 3) == 0) rowlen[r] = len;
+    for (int q = threadIdx.x & 3; q < NMAX; q += 4) rowcodes[r][q] = q < len ? codes[b + q] : 0;
+  }
+
+  // ---- lane-private sequence2
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t j = J0 + lane;
+  const bool jvalid = j < n;
+  int32_t nj = 0;
+  uint32_t boff[NMAX];
+  {
+    const int64_t b = jvalid ? offsets[j] : 0;
+    nj = jvalid ? (int32_t)(offsets[j + 1] - b) : 0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) boff[c] = (c < nj ? (uint32_t)codes[b + c] : 0u) * (uint32_t)sizeof(Cell);
+  }
+  __syncthreads();
+
+  const int32_t ix_first = max(NEG - goe, NEG - ge);
+  const char *tab_bytes = reinterpret_cast<const char *>(tab);
+
+  for (int rr = 0; rr < K3_ROWS_PER_WAVE; ++rr) {
+    const int lr = wave * K3_ROWS_PER_WAVE + rr;
+    const int64_t i = I0 + lr;
+    if (i >= n) break;
+    if (J0 + 63 < i) continue;  // the whole wave is below the diagonal
+    const bool want_direct = allow_direct && i >= row_begin && i < row_end;
+    const bool want_mirror_any = allow_mirror && J0 < row_end && J0 + 63 >= row_begin;
+    if (!want_direct && !want_mirror_any) continue;
+    const int32_t m = rowlen[lr];
+
+    // row 0 of the DP (reference :222-235)
+    int32_t MG[NMAX], X[NMAX];
+    uint32_t P[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+      const int32_t iy0 = -go - c * ge;  // Iy[0][c+1] = -go - ((c+1)-1)*ge
+      MG[c] = max(NEG, iy0) - goe;       // max(M,Ix,Iy)[0][c+1] - goe, feeds row 1's diagonal
+      X[c] = NEG;
+      P[c] = (uint32_t)(c + 1);          // 0 matches, length c+1
+    }
+    for (int32_t r = 1; r <= m; ++r) {
+      const uint32_t a = rowcodes[lr][r - 1];
+      const char *tab_row = tab_bytes + a * (24u * (uint32_t)sizeof(Cell));
+      // column-0 boundary of rows r-1 and r (reference :224-229)
+      const int32_t hb_prev = (r == 1) ? 0 : max(NEG, -go - (r - 2) * ge);  // max(M,Ix,Iy)[r-1][0]
+      const int32_t mg_diag0 = hb_prev - goe;
+      const uint32_t p_diag0 = (uint32_t)(r - 1), p_left0 = (uint32_t)r;
+      if (r == 1)
+        nw_row<NMAX, true>(MG, X, P, boff, tab_row, mg_diag0, p_diag0, p_left0, NEG - goe, NEG, ge, goe, ix_first);
+      else
+        nw_row<NMAX, false>(MG, X, P, boff, tab_row, mg_diag0, p_diag0, p_left0, NEG - goe, NEG, ge, goe, ix_first);
+    }
+
+    // ---- cell (m, nj)
+    uint32_t p = (uint32_t)m;  // nj == 0: length m, 0 matches (column-0 boundary)
+    int32_t sc = (m == 0) ? 0 : NEG;
+    if (m == 0) {              // no rows were run: the arrays still hold DP row 0
+      p = (uint32_t)nj;
+      sc = (nj == 0) ? 0 : NEG;
+    } else {
+#pragma unroll
+      for (int c = 0; c < NMAX; ++c)
+        if (nj == c + 1) { p = P[c]; sc = MG[c] + goe; }
+    }
+
+    if (!jvalid || j < i) continue;
+    const uint32_t mt = p >> 16, ln = p & 0xffffu;
+    const bool do_direct = want_direct;
+    const bool do_mirror = allow_mirror && (j != i) && j >= row_begin && j < row_end;
+    if (f64_out) {
+      double v = (double)mt / (double)ln;                    // reference :311
+      if (ln == 0) v = __longlong_as_double(0xFFF8000000000000ULL);  // 0/0 on the reference's host (x86 default NaN)
+      double *out = reinterpret_cast<double *>(out_v);
+      if (do_direct) out[(i - row_begin) * ld + j] = v;
+      if (do_mirror) out[(j - row_begin) * ld + i] = v;
+    } else {
+      const uint16_t v = (uint16_t)((mt << 8) | (ln & 0xffu));
+      uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
+      if (do_direct) out[(i - row_begin) * ld + j] = v;
+      if (do_mirror) out[(j - row_begin) * ld + i] = v;
+    }
+    if (score_out) {
+      if (do_direct) score_out[(i - row_begin) * ld_score + j] = sc;
+      if (do_mirror) score_out[(j - row_begin) * ld_score + i] = sc;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,
+                     hipStream_t stream) {
+  if (total <= 0) return DA_OK;
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(k_nw_encode, dim3((unsigned)blocks), dim3(256), 0, stream, d_res, total, d_codes, d_bad);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+const signed char *matrix_table_host(int id) {
+  return (id >= 0 && id < DA_NUM_MATRICES) ? da_matrix_data[id] : nullptr;
+}
+const char *matrix_name_host(int id) {
+  return (id >= 0 && id < DA_NUM_MATRICES) ? da_matrix_names[id] : nullptr;
+}
+int matrix_count_host() { return DA_NUM_MATRICES; }
+
+int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,
+              int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
+              bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
+              int64_t ld_score, hipStream_t stream) {
+  if (n <= 0 || row_end <= row_begin) return DA_OK;
+  const signed char *tab = matrix_table_host(matrix_id);
+  if (!tab) return fail(DA_ERR_BAD_ARG, "matrix id %d out of range", matrix_id);
+  if (max_len > 32)
+    return fail(DA_ERR_UNSUPPORTED,
+                "similarityNW on gfx950 currently handles sequences up to 32 residues "
+                "(longest here: %lld); the long-sequence kernel is not built yet",
+                (long long)max_len);
+  if (kind == DA_OUT_COMPACT && max_len > 127)
+    return fail(DA_ERR_UNSUPPORTED, "compact NW output needs alignment length <= 255");
+  ScoreTable st;
+  for (int e = 0; e < 576; ++e) st.s[e] = tab[e];
+  const int T = (int)ceil_div(n, K3_TILE);
+  int64_t ntiles;
+  if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
+  else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
+  if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
+  dim3 grid((unsigned)ntiles), block(K3_THREADS);
+  const int f64 = kind == DA_OUT_F64;
+#define DA_K3(NM)                                                                                   \
+  hipLaunchKernelGGL(k_nw_short<NM>, grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
+                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, f64, d_out, ld, d_score, \
+                     ld_score, ntiles, T)
+  if (max_len <= 8) DA_K3(8);
+  else if (max_len <= 12) DA_K3(12);
+  else if (max_len <= 16) DA_K3(16);
+  else if (max_len <= 20) DA_K3(20);
+  else if (max_len <= 24) DA_K3(24);
+  else DA_K3(32);
+#undef DA_K3
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+}  // namespace da

@@ -1,0 +1,129 @@
+"""Device-resident front end: torch tensors in, torch tensors out.
+
+PyTorch is plumbing here (HBM allocation, the current HIP stream,
+torch.distributed); every computation is a launch of the library's HIP kernels
+through the ``da_dev_*`` entry points of include/dynaalign.h.  Calls are
+asynchronous on ``torch.cuda.current_stream()``.
+"""
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import DA_OUT_COMPACT, DA_OUT_F64
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise _capi.DynaAlignError(_capi.DA_ERR_NO_DEVICE, "%s must live in HBM (dynaalign_amd has no CPU path)" % name)
+
+
+class DeviceSequences:
+    """Packed sequences resident in HBM: residues uint8[total], offsets int64[n+1]."""
+
+    def __init__(self, residues, offsets, device="cuda"):
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        self.n = len(offsets) - 1
+        self.total = int(offsets[-1]) if self.n >= 0 else 0
+        lens = np.diff(offsets) if self.n > 0 else np.zeros(0, np.int64)
+        self.max_len = int(lens.max()) if self.n > 0 else 0
+        self.offsets_host = offsets
+        res = np.ascontiguousarray(residues, np.uint8)[:max(self.total, 1)]
+        self.residues = torch.from_numpy(res.copy()).to(device)
+        self.offsets = torch.from_numpy(offsets.copy()).to(device)
+        self.codes = None  # filled by nw_encode
+
+
+def sig_ld(n_hash):
+    return int(_capi.load().da_sig_ld(int(n_hash)))
+
+
+def minhash_signatures(ds, k, n_hash, seeds, out=None):
+    """K1.  Returns an int32 tensor (n, sig_ld(n_hash)) holding the uint32 signatures
+    in columns [0, n_hash)."""
+    lib = _capi.load()
+    if not torch.is_tensor(seeds):
+        seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32).copy()).to(ds.residues.device)
+    _require_cuda(ds.residues, "residues")
+    ld = sig_ld(n_hash) if n_hash > 0 else 32
+    if out is None:
+        out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
+    _capi.check(lib.da_dev_minhash_signatures(ds.residues.data_ptr(), ds.offsets.data_ptr(), ds.n, ds.total,
+                                              ds.max_len, int(k), int(n_hash), seeds.data_ptr(), out.data_ptr(),
+                                              out.stride(0), _stream()))
+    return out
+
+
+def _alloc_out(rows, n, kind, device, out):
+    if out is not None:
+        return out
+    dt = torch.float64 if kind == DA_OUT_F64 else torch.int16  # int16 holds the uint16 bit pattern
+    return torch.empty((max(rows, 1), max(n, 1)), dtype=dt, device=device)
+
+
+def mh_compare(sig, n, n_hash, row_begin=0, row_end=None, symmetric=None, kind=DA_OUT_F64, out=None):
+    """K2.  Rows [row_begin,row_end) of the n x n similarity (float64) or match-count
+    (uint16 in an int16 tensor) matrix."""
+    lib = _capi.load()
+    _require_cuda(sig, "signatures")
+    row_end = n if row_end is None else row_end
+    if symmetric is None:
+        symmetric = (row_begin == 0 and row_end == n)
+    out = _alloc_out(row_end - row_begin, n, kind, sig.device, out)
+    _capi.check(lib.da_dev_mh_compare(sig.data_ptr(), sig.stride(0), n, int(n_hash), row_begin, row_end,
+                                      1 if symmetric else 0, kind, out.data_ptr(), out.stride(0), _stream()))
+    return out
+
+
+def nw_encode(ds):
+    """K0.  Fills ds.codes; returns the int32 flag tensor (0 = all residues valid)."""
+    lib = _capi.load()
+    _require_cuda(ds.residues, "residues")
+    ds.codes = torch.empty_like(ds.residues)
+    bad = torch.zeros(1, dtype=torch.int32, device=ds.residues.device)
+    _capi.check(lib.da_dev_nw_encode(ds.residues.data_ptr(), ds.total, ds.codes.data_ptr(), bad.data_ptr(), _stream()))
+    return bad
+
+
+def decode_bad_position(flag_value):
+    """int from nw_encode's flag -> byte position of the first invalid residue, or None."""
+    return None if flag_value == 0 else (2 ** 31 - 1) - int(flag_value)
+
+
+def nw(ds, matrix_name="BLOSUM62", gap_open=10, gap_ext=4, row_begin=0, row_end=None, symmetric=None,
+       kind=DA_OUT_F64, out=None, score=None):
+    """K3.  ds.codes must be filled (nw_encode)."""
+    lib = _capi.load()
+    if ds.codes is None:
+        raise ValueError("call nw_encode(ds) first")
+    mid = lib.da_matrix_id(matrix_name.encode("latin-1"))
+    if mid < 0:
+        _capi.check(_capi.DA_ERR_BAD_MATRIX)
+    n = ds.n
+    row_end = n if row_end is None else row_end
+    if symmetric is None:
+        symmetric = (row_begin == 0 and row_end == n)
+    out = _alloc_out(row_end - row_begin, n, kind, ds.residues.device, out)
+    _capi.check(lib.da_dev_nw(ds.codes.data_ptr(), ds.offsets.data_ptr(), n, ds.max_len, mid, int(gap_open),
+                              int(gap_ext), row_begin, row_end, 1 if symmetric else 0, kind, out.data_ptr(),
+                              out.stride(0), None if score is None else score.data_ptr(),
+                              0 if score is None else score.stride(0), _stream()))
+    return out
+
+
+def symmetrize(mat, n, kind=DA_OUT_F64):
+    _capi.check(_capi.load().da_dev_symmetrize(mat.data_ptr(), n, mat.stride(0), kind, _stream()))
+    return mat
+
+
+def widen(compact, is_nw, n_hash=0, out=None):
+    """uint16 block (int16 tensor) -> float64 with the reference's divide."""
+    if out is None:
+        out = torch.empty(compact.shape, dtype=torch.float64, device=compact.device)
+    assert compact.is_contiguous() and out.is_contiguous()
+    _capi.check(_capi.load().da_dev_widen(compact.data_ptr(), out.data_ptr(), compact.numel(), 1 if is_nw else 0,
+                                          int(n_hash), _stream()))
+    return out

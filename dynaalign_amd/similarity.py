@@ -1,0 +1,170 @@
+"""Host-side mirror of the reference's R interface for the hot path.
+
+    similarityMH(sequences, k=4, n_hash=50)                      reference R/RcppExports.R:15-17
+    similarityNW(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4)   reference R/RcppExports.R:34-36
+
+Same names, argument order, defaults and error texts as the reference; the
+bodies marshal to the C ABI (include/dynaalign.h) exactly as the Rcpp glue in
+r_glue/ does.  Results are dense symmetric n x n float64 matrices with
+``dimnames`` ("1".."n", reference src/minHash.cpp:181-185,
+src/pairwiseSeqAlign.cpp:356-362).
+
+Seeds: the reference draws its hash seeds from ``std::random_device``
+(src/minHash.cpp:73,137), so it is non-deterministic by construction.  The
+default here does the same.  For reproducible runs set ``seed=`` (keyword-only
+extension), ``set_option("seed", s)`` or the environment variable
+``DYNAALIGN_SEED``; the seed is expanded with the reference's own rule
+(``HashFamily(n_hash, seed)``, src/minHash.cpp:73-81).
+"""
+import os
+
+import numpy as np
+
+from . import _capi
+
+_OPTIONS = {"seed": None}
+
+
+def set_option(name, value):
+    if name not in _OPTIONS:
+        raise KeyError(name)
+    _OPTIONS[name] = value
+
+
+def get_option(name):
+    return _OPTIONS[name]
+
+
+class SimilarityMatrix(np.ndarray):
+    """float64 (n, n) ndarray carrying R-style ``dimnames``."""
+
+    def __new__(cls, arr):
+        obj = np.asarray(arr).view(cls)
+        n = obj.shape[0]
+        labels = [str(i + 1) for i in range(n)]
+        obj.dimnames = [labels, list(labels)]
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.dimnames = getattr(obj, "dimnames", None)
+
+
+def pack_sequences(sequences):
+    """Character vector -> (residues uint8[total], offsets int64[n+1]).
+
+    Bytes are taken as they are (no case folding, no re-encoding), like
+    ``as<std::string>`` on a CHARSXP (reference src/minHash.cpp:147)."""
+    if isinstance(sequences, (str, bytes)):
+        sequences = [sequences]
+    bs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in sequences]
+    off = np.zeros(len(bs) + 1, np.int64)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=off[1:])
+    total = int(off[-1])
+    res = np.frombuffer(b"".join(bs), np.uint8).copy() if total else np.zeros(1, np.uint8)
+    return res, off
+
+
+def _as_int(x, name):
+    # R coerces numeric to int at the .Call boundary (Rcpp input_parameter<int>)
+    try:
+        return int(x)
+    except Exception:
+        raise TypeError("%s must be an integer" % name)
+
+
+def hash_family_seeds(seed, n_hash):
+    """seeds[h] = h-th raw std::mt19937(seed) output (reference src/minHash.cpp:75-80)."""
+    lib = _capi.load()
+    out = np.zeros(max(int(n_hash), 1), np.uint32)
+    _capi.check(lib.da_hash_family_seeds(int(seed) & 0xFFFFFFFF, int(n_hash), out.ctypes.data))
+    return out[:n_hash]
+
+
+def _resolve_seed(seed):
+    if seed is None:
+        seed = _OPTIONS["seed"]
+    if seed is None and os.environ.get("DYNAALIGN_SEED"):
+        seed = int(os.environ["DYNAALIGN_SEED"])
+    if seed is None:
+        seed = _capi.load().da_random_seed()  # reference default: std::random_device{}()
+    return int(seed) & 0xFFFFFFFF
+
+
+def _mh_prelude(sequences, k, n_hash, seed):
+    lib = _capi.load()
+    res, off = pack_sequences(sequences)
+    n = len(off) - 1
+    k, n_hash = _as_int(k, "k"), _as_int(n_hash, "n_hash")
+    # validation (and its order) lives in the library; seeds are only needed when it passes
+    seeds = hash_family_seeds(_resolve_seed(seed), n_hash) if n_hash > 0 else np.zeros(1, np.uint32)
+    if len(seeds) == 0:
+        seeds = np.zeros(1, np.uint32)
+    return lib, res, off, n, k, n_hash, seeds
+
+
+def similarityMH(sequences, k=4, n_hash=50, *, seed=None):
+    """MinHash-estimated Jaccard similarity of k-mer sets, all pairs.
+
+    Mirrors reference ``similarityMH`` (src/minHash.cpp:119-188): errors
+    "Input sequences vector cannot be empty" / "'k' must be a positive integer" /
+    "Number of hash functions must be positive" in that order; diagonal 1.0."""
+    lib, res, off, n, k, n_hash, seeds = _mh_prelude(sequences, k, n_hash, seed)
+    out = np.empty((max(n, 1), max(n, 1)), np.float64)
+    _capi.check(lib.da_similarity_mh(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
+                                     out.ctypes.data))
+    return SimilarityMatrix(out[:n, :n])
+
+
+def minhash_signatures(sequences, k=4, n_hash=50, *, seed=None):
+    """The (n, n_hash) uint32 signature matrix (reference src/minHash.cpp:140-157)."""
+    lib, res, off, n, k, n_hash, seeds = _mh_prelude(sequences, k, n_hash, seed)
+    out = np.empty((max(n, 1), max(n_hash, 1)), np.uint32)
+    _capi.check(lib.da_minhash_signatures(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
+                                          out.ctypes.data))
+    return out[:n, :n_hash]
+
+
+def mh_counts(sequences, k=4, n_hash=50, *, seed=None, row_begin=0, row_end=None):
+    """uint16 match counts (numerator at reference src/minHash.cpp:168-174) for a row block."""
+    lib, res, off, n, k, n_hash, seeds = _mh_prelude(sequences, k, n_hash, seed)
+    row_end = n if row_end is None else row_end
+    out = np.empty((max(row_end - row_begin, 1), max(n, 1)), np.uint16)
+    _capi.check(lib.da_mh_counts(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
+                                 row_begin, row_end, out.ctypes.data))
+    return out[:max(row_end - row_begin, 0), :n]
+
+
+def similarityNW(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4):
+    """Fraction identity (matches / alignment length) of the reference's
+    affine-gap global alignment, all pairs.
+
+    Mirrors reference ``similarityNW`` (src/pairwiseSeqAlign.cpp:331-365): no input
+    validation beyond "Invalid substitution matrix name: %s" and the lazily raised
+    "Invalid amino acid in sequence1/2: %c"; n == 0 gives a 0 x 0 matrix."""
+    lib = _capi.load()
+    res, off = pack_sequences(sequences)
+    n = len(off) - 1
+    out = np.empty((max(n, 1), max(n, 1)), np.float64)
+    name = matrixName.encode("latin-1") if isinstance(matrixName, str) else bytes(matrixName)
+    _capi.check(lib.da_similarity_nw(res.ctypes.data, off.ctypes.data, n, name, _as_int(gapOpen, "gapOpen"),
+                                     _as_int(gapExt, "gapExt"), out.ctypes.data))
+    return SimilarityMatrix(out[:n, :n])
+
+
+def nw_pairs(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4, *, row_begin=0, row_end=None):
+    """(matches, length, score) int32 arrays for a row block: the integers the
+    reference divides at src/pairwiseSeqAlign.cpp:311, plus M[m][n]."""
+    lib = _capi.load()
+    res, off = pack_sequences(sequences)
+    n = len(off) - 1
+    row_end = n if row_end is None else row_end
+    r = max(row_end - row_begin, 0)
+    mt = np.zeros((max(r, 1), max(n, 1)), np.int32)
+    ln = np.zeros_like(mt)
+    sc = np.zeros_like(mt)
+    name = matrixName.encode("latin-1") if isinstance(matrixName, str) else bytes(matrixName)
+    _capi.check(lib.da_nw_pairs(res.ctypes.data, off.ctypes.data, n, name, _as_int(gapOpen, "gapOpen"),
+                                _as_int(gapExt, "gapExt"), row_begin, row_end, mt.ctypes.data, ln.ctypes.data,
+                                sc.ctypes.data))
+    return mt[:r, :n], ln[:r, :n], sc[:r, :n]

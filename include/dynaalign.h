@@ -1,0 +1,179 @@
+/*
+ * dynaalign.h -- C ABI of libdynaalign_hip.so (MI355X / gfx950 HIP kernels).
+ *
+ * This is the drop-in boundary for DynaAlign's all-pairs similarity hot path.
+ * The reference crosses from R into native code through two Rcpp-generated
+ * .Call entry points (reference src/RcppExports.cpp:15-25 and :28-39) that
+ * convert SEXPs and call
+ *     NumericMatrix similarityMH(CharacterVector, int k, int n_hash)
+ *                                        reference src/minHash.cpp:119-188
+ *     NumericMatrix similarityNW(CharacterVector, std::string, int, int)
+ *                                        reference src/pairwiseSeqAlign.cpp:331-365
+ * The functions below replace the BODIES of those two functions.  The R-level
+ * signatures (reference R/RcppExports.R:15-17, :34-36) and the .Call symbols
+ * stay exactly as they are; the Rcpp glue that binds them to this ABI is in
+ * r_glue/ and described in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions, no library-owned memory crosses.
+ *   - sequences are passed packed: `residues` holds the raw bytes of all
+ *     sequences back to back, `offsets[i]..offsets[i+1]` delimits sequence i
+ *     (n+1 entries).  This is what the glue builds once from the STRSXP
+ *     (the reference instead copies per element: src/minHash.cpp:147,
+ *     src/pairwiseSeqAlign.cpp:341-343).
+ *   - every function returns DA_OK (0) or a DA_ERR_* code; da_last_error()
+ *     returns the message for the calling thread.  For the reference's own
+ *     error conditions the message text is the reference's, verbatim.
+ *   - N x N results are symmetric, so row- and column-major coincide: `out`
+ *     may be R's REAL() pointer (reference allocates NumericMatrix(n,n) at
+ *     src/minHash.cpp:134 / src/pairwiseSeqAlign.cpp:335).
+ *   - "host" functions take host pointers and do their own H2D/D2H; "dev"
+ *     functions take DEVICE pointers (hipMalloc'ed by the caller, e.g. a
+ *     torch tensor's data_ptr()) plus a hipStream_t passed as void*, launch
+ *     asynchronously on that stream and never synchronise.
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with DA_ERR_NO_DEVICE.
+ */
+#ifndef DYNAALIGN_H
+#define DYNAALIGN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DA_ABI_VERSION 1
+
+enum da_status {
+  DA_OK = 0,
+  DA_ERR_EMPTY_INPUT = 1,      /* "Input sequences vector cannot be empty"     src/minHash.cpp:121-123 */
+  DA_ERR_BAD_K = 2,            /* "'k' must be a positive integer"             src/minHash.cpp:125-127 */
+  DA_ERR_BAD_NHASH = 3,        /* "Number of hash functions must be positive"  src/minHash.cpp:129-131 */
+  DA_ERR_BAD_MATRIX = 4,       /* "Invalid substitution matrix name: %s"       src/pairwiseSeqAlign.cpp:204 */
+  DA_ERR_BAD_RESIDUE_SEQ1 = 5, /* "Invalid amino acid in sequence1: %c"        src/pairwiseSeqAlign.cpp:241-243 */
+  DA_ERR_BAD_RESIDUE_SEQ2 = 6, /* "Invalid amino acid in sequence2: %c"        src/pairwiseSeqAlign.cpp:248-250 */
+  DA_ERR_NOMEM = 7,
+  DA_ERR_NO_DEVICE = 8,        /* no HIP device / runtime: the product has no CPU path */
+  DA_ERR_HIP = 9,              /* a HIP call failed; message carries hipGetErrorString */
+  DA_ERR_UNSUPPORTED = 10,     /* outside what the gfx950 kernels implement (message says what) */
+  DA_ERR_BAD_ARG = 11
+};
+
+/* element type of a device-side similarity block */
+enum da_out_kind {
+  DA_OUT_F64 = 0,    /* double: MH matches/n_hash (src/minHash.cpp:174), NW matches/len (src/pairwiseSeqAlign.cpp:311) */
+  DA_OUT_COMPACT = 1 /* uint16: MH match count; NW (matches << 8 | len) -- valid for len <= 255 */
+};
+
+const char *da_last_error(void);
+const char *da_status_message(int status); /* static text for a code ("" if none) */
+int da_abi_version(void);
+int da_device_count(void); /* 0 when no HIP device is usable */
+
+/* ---- HashFamily (reference src/minHash.cpp:67-89) ------------------------ */
+
+/* seeds_out[h] = h-th raw output of std::mt19937(seed)  (src/minHash.cpp:75-80). */
+int da_hash_family_seeds(uint32_t seed, int n_hash, uint32_t *seeds_out);
+/* what the reference's default argument does: std::random_device{}() (src/minHash.cpp:73). */
+uint32_t da_random_seed(void);
+
+/* ---- host-pointer entry points (what the Rcpp glue calls) ---------------- */
+
+/* similarityMH body (src/minHash.cpp:119-188).  `seeds` = n_hash hash seeds
+ * (da_hash_family_seeds); validation order and messages as :121-131.
+ * out: n*n doubles, diagonal exactly 1.0 (:161). */
+int da_similarity_mh(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                     int k, int n_hash, const uint32_t *seeds, double *out);
+
+/* The signature matrix alone (src/minHash.cpp:140-157): sig_out[n][n_hash]. */
+int da_minhash_signatures(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                          int k, int n_hash, const uint32_t *seeds, uint32_t *sig_out);
+
+/* Integer match counts (the numerator at src/minHash.cpp:168-174) for rows
+ * [row_begin,row_end) x all n columns; counts_out[rows][n]; diagonal = n_hash.
+ * Requires n_hash <= 65535. */
+int da_mh_counts(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                 int k, int n_hash, const uint32_t *seeds,
+                 int64_t row_begin, int64_t row_end, uint16_t *counts_out);
+
+/* similarityNW body (src/pairwiseSeqAlign.cpp:331-365): BLOSUM name lookup
+ * (:190-206), pair (i,j), i<=j, evaluated as calc(seq[i], seq[j]) (:340-346),
+ * mirrored (:349-350), diagonal computed.  n == 0 returns DA_OK and writes
+ * nothing (the reference returns a 0x0 matrix).  Residue errors reproduce the
+ * reference's first-raised message (lazy row-major validation, :238-250). */
+int da_similarity_nw(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                     const char *matrix_name, int gap_open, int gap_ext, double *out);
+
+/* The integers behind similarityNW for rows [row_begin,row_end) x all n
+ * columns, each entry for calc(seq[min(i,j)], seq[max(i,j)]):
+ *   matches_out / len_out : the two operands of the divide at :311
+ *   score_out             : M[m][n] after the fill (:268-278), never exposed
+ *                           by the reference -- auxiliary, may be NULL.
+ * Arrays are [rows][n] int32; any may be NULL. */
+int da_nw_pairs(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                const char *matrix_name, int gap_open, int gap_ext,
+                int64_t row_begin, int64_t row_end,
+                int32_t *matches_out, int32_t *len_out, int32_t *score_out);
+
+/* ---- device-pointer entry points (bench / multi-GPU sharding) ------------ */
+
+/* Leading dimension (in uint32 elements) the library uses for signature
+ * matrices: n_hash rounded up to a multiple of 32, so that every row starts
+ * 16-byte aligned for the compare kernel's vector loads. */
+int64_t da_sig_ld(int n_hash);
+
+/* K1: signature build.  d_sig holds n rows of ld_sig (>= n_hash) uint32;
+ * columns [n_hash, ld_sig) are not written. */
+int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n,
+                              int64_t total_residues, int64_t max_len,
+                              int k, int n_hash, const uint32_t *d_seeds,
+                              uint32_t *d_sig, int64_t ld_sig, void *stream);
+
+/* K2: all-pairs signature compare.
+ * Computes rows [row_begin,row_end) of the n x n result into d_out, which
+ * holds (row_end-row_begin) rows of leading dimension ld (>= n) elements.
+ *   symmetric != 0 : requires row_begin == 0, row_end == n; only tiles on or
+ *                    above the diagonal are compared and each is stored twice
+ *                    (direct + mirrored), like src/minHash.cpp:175-176.
+ *   symmetric == 0 : every (i,j) of the row block is compared (row-sharding).
+ * kind selects double or uint16 counts.  Diagonal = 1.0 / n_hash.
+ * d_sig must be 16-byte aligned with ld_sig % 4 == 0 (use da_sig_ld). */
+int da_dev_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+                      int64_t row_begin, int64_t row_end, int symmetric,
+                      int kind, void *d_out, int64_t ld, void *stream);
+
+/* K0: validate + encode residues to BLOSUM row indices 0..23
+ * (src/pairwiseSeqAlign.cpp:15-21).  d_codes[total]; *d_bad (int32, caller
+ * zeroes it) becomes INT32_MAX - (smallest offending byte position) if any
+ * byte is not one of ARNDCQEGHILKMFPSTWYVBZX*, and stays 0 otherwise. */
+int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues,
+                     uint8_t *d_codes, int32_t *d_bad, void *stream);
+
+/* K3: all-pairs NW identity.  Same row-block / symmetric / ld conventions as
+ * da_dev_mh_compare.  d_codes from da_dev_nw_encode.  kind: double ratio or
+ * uint16 (matches<<8|len).  d_score (int32, same shape, ld_score) may be NULL.
+ * max_len = longest sequence (host knows it from offsets). */
+int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len,
+              int matrix_id, int gap_open, int gap_ext,
+              int64_t row_begin, int64_t row_end, int symmetric,
+              int kind, void *d_out, int64_t ld, int32_t *d_score, int64_t ld_score,
+              void *stream);
+
+/* name -> id for da_dev_nw; -1 + DA_ERR_BAD_MATRIX message when unknown. */
+int da_matrix_id(const char *matrix_name);
+
+/* Fill the strict lower triangle of an n x n device matrix from its upper
+ * triangle (after a row-sharded gather of upper-triangular row blocks). */
+int da_dev_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, void *stream);
+
+/* Widen a compact uint16 block to double on the device:
+ *   MH: count / n_hash      NW: (v >> 8) / (v & 255)
+ * `is_nw` selects the rule; n_hash ignored for NW. */
+int da_dev_widen(const uint16_t *d_in, double *d_out, int64_t count, int is_nw, int n_hash, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNAALIGN_H */

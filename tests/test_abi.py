@@ -1,0 +1,153 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/dynaalign.h declares, validates like the reference, and refuses to compute
+without a GPU (no CPU fallback).  No compute calls are made here."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    from dynaalign_amd import _capi
+    return _capi.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from dynaalign_amd import _capi
+    declared = _capi.header_symbols()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), name
+    # the Python binding covers the header exactly
+    assert sorted(_capi.SIGNATURES) == declared
+    assert lib.da_abi_version() == 1
+
+
+def test_no_torch_types_or_cxx_in_header():
+    from dynaalign_amd import _capi
+    import re
+    txt = open(_capi.HEADER_PATH).read()
+    assert 'extern "C"' in txt
+    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)  # declarations only, comments stripped
+    for banned in ("torch", "at::", "std::", "template", "class "):
+        assert banned not in code, banned
+    # the header compiles as plain C
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", _capi.HEADER_PATH])
+
+
+def test_library_does_not_link_the_oracle(lib):
+    from dynaalign_amd import _capi
+    out = subprocess.check_output(["readelf", "-d", _capi.LIB_PATH]).decode()
+    assert "liborc" not in out
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", _capi.LIB_PATH]).decode()
+    assert "orc_" not in syms
+
+
+def test_hash_family_seeds_match_mt19937(lib, kats):
+    import dynaalign_amd as da
+    for kat in kats["mt19937"]:
+        if "first" in kat:
+            assert da.hash_family_seeds(kat["seed"], len(kat["first"])).tolist() == kat["first"]
+        else:
+            assert int(da.hash_family_seeds(kat["seed"], kat["index"] + 1)[kat["index"]]) == kat["value"]
+    assert np.array_equal(da.hash_family_seeds(12345, 500), O.seeds(12345, 500))
+    assert len(da.hash_family_seeds(7, 0)) == 0
+
+
+def test_synth_stream_is_mt19937():
+    from dynaalign_amd import synth
+    assert np.array_equal(synth.mt19937_raw(1, 700), O.seeds(1, 700))
+    res, off = synth.uniform_peptides(10, 20, seed=7)
+    draws = O.seeds(7, 200)
+    assert bytes(res) == bytes(synth.AA20[draws % 20])
+    assert off.tolist() == list(range(0, 201, 20))
+    r2, o2 = synth.h3n2_like(50, 20)
+    assert len(r2) == 1000 and set(bytes(r2)) <= set(b"ACDEFGHIKLMNPQRSTVWY")
+    assert np.array_equal(r2, synth.h3n2_like(50, 20)[0])
+
+
+def test_reference_error_messages_and_order(lib, kats):
+    """Same validation order and texts as reference src/minHash.cpp:121-131 and
+    src/pairwiseSeqAlign.cpp:204,242,249 -- raised before any device is needed."""
+    import dynaalign_amd as da
+    e = kats["mh_errors"]
+    with pytest.raises(da.DynaAlignError, match="^" + e["empty"] + "$") as ei:
+        da.similarityMH([], 0, 0)
+    assert ei.value.code == 1
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityMH(["ACDE"], 0, 0)
+    assert (ei.value.code, str(ei.value)) == (2, e["k"])
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityMH(["ACDE"], 4, -3)
+    assert (ei.value.code, str(ei.value)) == (3, e["n_hash"])
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityNW(["AA"], "PAM250")
+    assert (ei.value.code, str(ei.value)) == (4, kats["nw_bad_matrix"]["error"])
+    # matrix name is checked before the (possibly empty) input, like the reference (:338)
+    with pytest.raises(da.DynaAlignError):
+        da.similarityNW([], "nope")
+    assert da.similarityNW([]).shape == (0, 0)
+
+
+@pytest.mark.parametrize("seqs", [
+    ["AJ", "AA"], ["AA", "AJ"], ["JA", "AA"], ["", "AJ", "AA"], ["", "", "J"], ["AA", "CC", "AUA", "JJ"],
+    ["AA", "a"], ["A A"], ["AC", "", "C1"], ["", "J", "AA"],
+])
+def test_nw_residue_errors_match_the_lazy_reference_order(lib, seqs):
+    """The library validates up front but must raise what the reference's lazy row-major
+    fill would raise first; the oracle implements that lazily."""
+    import dynaalign_amd as da
+    rc, _, msg = O.similarity_nw(seqs)
+    assert rc in (O.ERR_BAD_RES1, O.ERR_BAD_RES2)
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityNW(seqs)
+    assert (ei.value.code, str(ei.value)) == (rc, msg)
+
+
+def test_nw_errors_fuzz(lib):
+    import dynaalign_amd as da
+    rng = np.random.RandomState(5)
+    alpha = "ARNDCQEGHILKMFPSTWYVBZX*" * 3 + "JUO"
+    for _ in range(200):
+        seqs = ["".join(alpha[i] for i in rng.randint(0, len(alpha), rng.randint(0, 6))) for _ in range(rng.randint(1, 6))]
+        rc, _, msg = O.similarity_nw(seqs)
+        if rc == 0:
+            continue
+        with pytest.raises(da.DynaAlignError) as ei:
+            da.similarityNW(seqs)
+        assert (ei.value.code, str(ei.value)) == (rc, msg), seqs
+
+
+def test_compute_fails_loudly_without_gpu(lib):
+    import dynaalign_amd as da
+    if lib.da_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityMH(["ACDEFG", "ACDEFH"], 4, 8, seed=1)
+    assert ei.value.code == 8 and "no CPU fallback" in str(ei.value)
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityNW(["ACDEFG", "ACDEFH"])
+    assert ei.value.code == 8
+
+
+def test_pack_sequences_layout():
+    import dynaalign_amd as da
+    res, off = da.pack_sequences(["AC", "", "DEF"])
+    assert off.tolist() == [0, 2, 2, 5] and bytes(res) == b"ACDEF"
+    res, off = da.pack_sequences([])
+    assert off.tolist() == [0]
+
+
+def test_product_package_never_imports_the_oracle():
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "dynaalign_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"oracle_lib|liborc|dynaalign_oracle|orc_", txt), os.path.join(dirpath, f)

@@ -1,0 +1,268 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs, against the committed golden fixtures, and
+-- at BASELINE sizes -- through size-independent properties.
+
+Bars: bit-exact for signatures, match counts, NW (matches, length, score); bit-exact float64
+(compared as uint64) for the similarity matrices -- they are one IEEE divide of two exactly
+representable integers (reference src/minHash.cpp:174, src/pairwiseSeqAlign.cpp:311)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def da(built):
+    import dynaalign_amd
+    from dynaalign_amd import _capi
+    lib = _capi.load()
+    assert lib.da_device_count() > 0, "no HIP device visible: the product has no CPU fallback"
+    return dynaalign_amd
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def assert_same_f64(got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape
+    assert np.array_equal(bits(got), bits(want)), "float64 bit patterns differ at %s" % (
+        np.argwhere(bits(got) != bits(want))[:5].tolist(),)
+
+
+# ---------------------------------------------------------------- MinHash
+
+def test_native_library_is_loaded(da):
+    from dynaalign_amd import _capi
+    maps = open("/proc/self/maps").read()
+    assert "libdynaalign_hip.so" in maps
+    assert _capi.load().da_device_count() >= 1
+
+
+def test_signature_known_answers_on_gpu(da, kats):
+    for kat in kats["signatures"]:
+        sig = da.minhash_signatures([kat["sequence"]], kat["k"], kat["n_hash"], seed=kat["seed"])
+        assert sig[0].tolist() == kat["sig"]
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("n_hash", [8, 50, 500])
+def test_signatures_and_counts_match_golden(da, golden, k, n_hash):
+    """edge cases: empty, L<k, L=k, repeated k-mers, non-AA bytes, duplicates"""
+    seqs = [str(s) for s in golden["mh_sequences"]]
+    sig = da.minhash_signatures(seqs, k, n_hash, seed=12345)
+    assert np.array_equal(sig, golden["mh_sig_k%d_h%d" % (k, n_hash)])
+    cnt = da.mh_counts(seqs, k, n_hash, seed=12345)
+    assert np.array_equal(cnt, golden["mh_cnt_k%d_h%d" % (k, n_hash)])
+    M = da.similarityMH(seqs, k, n_hash, seed=12345)
+    assert_same_f64(M, golden["mh_cnt_k%d_h%d" % (k, n_hash)].astype(np.float64) / n_hash)
+
+
+@pytest.mark.parametrize("n,k,n_hash", [(1, 4, 50), (2, 4, 500), (127, 4, 500), (128, 2, 50), (129, 4, 33),
+                                        (300, 3, 7), (641, 2, 50), (1000, 4, 500), (1025, 6, 129)])
+def test_similarity_mh_matches_oracle(da, evp, n, k, n_hash):
+    from dynaalign_amd import synth
+    if n == 641:
+        seqs = evp                      # config 1: the bundled evp_peparray probes, k=2 n_hash=50
+    else:
+        seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+    seeds = da.hash_family_seeds(12345, n_hash)
+    rc, want = O.similarity_mh(seqs, k, n_hash, seeds)
+    assert rc == 0
+    got = da.similarityMH(seqs, k, n_hash, seed=12345)
+    assert_same_f64(got, want)
+    assert got.dimnames[0][0] == "1" and got.dimnames[1][-1] == str(n)
+    assert np.all(np.diag(got) == 1.0)
+
+
+def test_mh_long_and_ragged_sequences(da):
+    rng = np.random.RandomState(11)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = ["".join(aa[i] for i in rng.randint(0, 20, L)) for L in (0, 3, 566, 1500, 2500, 40, 567, 1, 4, 1024, 1027)]
+    for k, n_hash in ((4, 50), (5, 300), (9, 64), (2, 257)):
+        seeds = da.hash_family_seeds(99, n_hash)
+        assert np.array_equal(da.minhash_signatures(seqs, k, n_hash, seed=99), O.signatures(seqs, k, n_hash, seeds))
+        rc, want = O.similarity_mh(seqs, k, n_hash, seeds)
+        assert_same_f64(da.similarityMH(seqs, k, n_hash, seed=99), want)
+
+
+def test_mh_row_blocks_and_forced_streaming(da, monkeypatch):
+    """row-sharded entry (rect tiles) and the host path's row-block streaming give the same bits"""
+    from dynaalign_amd import synth
+    seqs = synth.to_strings(*synth.h3n2_like(700, 20))
+    seeds = da.hash_family_seeds(12345, 500)
+    sig = O.signatures(seqs, 4, 500, seeds)
+    want = O.mh_counts(sig)
+    for r0, r1 in ((0, 700), (0, 128), (128, 384), (130, 131), (515, 700), (699, 700)):
+        got = da.mh_counts(seqs, 4, 500, seed=12345, row_begin=r0, row_end=r1)
+        assert np.array_equal(got, want[r0:r1]), (r0, r1)
+    monkeypatch.setenv("DYNAALIGN_BLOCK_BYTES", str(700 * 8 * 200))   # forces 128-row blocks
+    got = da.similarityMH(seqs, 4, 500, seed=12345)
+    assert_same_f64(got, want.astype(np.float64) / 500)
+
+
+def test_mh_default_seed_is_random_but_valid(da):
+    seqs = ["ACDEFGHIKL", "ACDEFGHIKL", "WWWWWYYYYY"]
+    a = da.similarityMH(seqs, 4, 64)
+    assert a[0, 1] == 1.0 and a[0, 2] == 0.0 and np.array_equal(a, a.T)
+    da.set_option("seed", 77)
+    try:
+        b = da.similarityMH(seqs, 4, 64)
+        rc, want = O.similarity_mh(seqs, 4, 64, da.hash_family_seeds(77, 64))
+        assert_same_f64(b, want)
+    finally:
+        da.set_option("seed", None)
+
+
+def test_device_divide_table_is_ieee(da):
+    """count/n_hash computed on the device == host IEEE divide for every count"""
+    import torch
+    from dynaalign_amd import device
+    for n_hash in (1, 3, 50, 500, 4095, 4096, 65535):
+        c = np.arange(0, n_hash + 1, max(1, n_hash // 5000)).astype(np.uint16)
+        t = torch.from_numpy(c.view(np.int16).copy()).cuda()
+        got = device.widen(t, False, n_hash).cpu().numpy()
+        assert_same_f64(got, c.astype(np.float64) / n_hash)
+    v = np.array([(m << 8) | l for l in range(1, 256) for m in range(0, min(l, 127) + 1)], np.uint16)
+    t = torch.from_numpy(v.view(np.int16).copy()).cuda()
+    got = device.widen(t, True).cpu().numpy()
+    assert_same_f64(got, (v >> 8).astype(np.float64) / (v & 255).astype(np.float64))
+
+
+# ---------------------------------------------------------------- NW
+
+NW_CASES = [("BLOSUM62", 10, 4), ("BLOSUM45", 10, 4), ("BLOSUM50", 12, 2), ("BLOSUM80", 0, 0),
+            ("BLOSUM90", 5, 1), ("BLOSUM100", 10, 4), ("BLOSUM62", 1, 7), ("BLOSUM62", 3, 0)]
+
+
+@pytest.mark.parametrize("name,go,ge", NW_CASES)
+def test_nw_integers_match_golden(da, golden, name, go, ge):
+    """ragged lengths 0..30, low-complexity strings (gaps), B/Z/X/*, all six matrices"""
+    seqs = [str(s) for s in golden["nw_sequences"]]
+    mt, ln, sc = da.nw_pairs(seqs, name, go, ge)
+    tag = "nw_%s_%d_%d" % (name, go, ge)
+    assert np.array_equal(mt, golden[tag + "_matches"])
+    assert np.array_equal(ln, golden[tag + "_len"])
+    assert np.array_equal(sc, golden[tag + "_score"])
+
+
+def test_nw_known_answers_on_gpu(da, kats):
+    q = kats["nw_4x4"]
+    M = da.similarityNW(q["sequences"], q["matrix"], q["gap_open"], q["gap_ext"])
+    assert np.round(np.asarray(M), 6).tolist() == q["rounded6"]
+    a = kats["nw_asymmetric"]
+    M = da.similarityNW([a["a"], a["b"]])
+    assert M[0, 1] == M[1, 0] == a["ab"][0] / a["ab"][1]
+    M = da.similarityNW([a["b"], a["a"]])          # lower index is sequence1
+    assert M[0, 1] == M[1, 0] == a["ba"][0] / a["ba"][1]
+
+
+def test_nw_empty_strings_and_nan_bits(da):
+    seqs = ["", "A", "", "ACD"]
+    rc, want, _ = O.similarity_nw(seqs)
+    got = da.similarityNW(seqs)
+    assert np.isnan(got[0, 0]) and np.isnan(got[0, 2]) and got[0, 1] == 0.0
+    assert_same_f64(got, want)                     # NaN payload/sign identical to the host divide
+    mt, ln, sc = da.nw_pairs(seqs)
+    rc, omt, oln, osc, _ = O.nw_rows(seqs)
+    assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc)
+    assert da.similarityNW([]).shape == (0, 0)
+
+
+def test_nw_evp_config1(da, kats, evp):
+    """config 1 input (641 bundled 12-mers) against the reference-recorded checksum"""
+    q = kats["nw_evp"]
+    W = np.asarray(da.similarityNW(evp))
+    assert abs(W[0, 1] - q["w01"]) < 1e-10 and abs(W[0, 2] - q["w02"]) < 1e-10
+    assert abs(W.sum() - q["sum_all"]) < 1e-6
+    rc, want, _ = O.similarity_nw(evp)
+    assert_same_f64(W, want)
+
+
+@pytest.mark.parametrize("n,L", [(1, 20), (63, 20), (64, 20), (65, 8), (200, 12), (333, 20), (130, 24), (100, 32)])
+def test_similarity_nw_matches_oracle(da, n, L):
+    from dynaalign_amd import synth
+    seqs = synth.to_strings(*synth.h3n2_like(n, L, parent_len=100))
+    rc, want, _ = O.similarity_nw(seqs)
+    assert rc == 0
+    got = da.similarityNW(seqs)
+    assert_same_f64(got, want)
+    assert got.dimnames[0][-1] == str(n)
+
+
+def test_nw_row_blocks(da):
+    from dynaalign_amd import synth
+    seqs = synth.to_strings(*synth.h3n2_like(300, 20))
+    seqs[17] = ""                                  # ragged
+    seqs[250] = seqs[250][:7]
+    rc, omt, oln, osc, _ = O.nw_rows(seqs)
+    for r0, r1 in ((0, 300), (0, 64), (64, 192), (70, 71), (130, 300), (299, 300)):
+        mt, ln, sc = da.nw_pairs(seqs, row_begin=r0, row_end=r1)
+        assert np.array_equal(mt, omt[r0:r1]) and np.array_equal(ln, oln[r0:r1]) and np.array_equal(sc, osc[r0:r1]), (r0, r1)
+
+
+def test_nw_large_gap_penalties(da):
+    """penalties far outside the usual range still agree (int32 arithmetic, NEG sentinel)"""
+    from dynaalign_amd import synth
+    seqs = synth.to_strings(*synth.uniform_peptides(80, 16, seed=3))
+    for go, ge in ((1000, 1000), (0, 50), (100000, 1), (7, 0)):
+        rc, omt, oln, osc, _ = O.nw_rows(seqs, 0, None, "BLOSUM62", go, ge)
+        mt, ln, sc = da.nw_pairs(seqs, "BLOSUM62", go, ge)
+        assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc), (go, ge)
+
+
+def test_nw_long_sequences_fail_loudly(da):
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityNW(["A" * 40, "C" * 10])
+    assert ei.value.code == 10 and "32" in str(ei.value)
+
+
+# ---------------------------------------------------------------- BASELINE sizes (properties)
+
+def test_mh_10k_properties_and_sampled_rows(da):
+    """config 2: 10k synthetic 20-mers, k=4, n_hash=500.  Full oracle compare of a row slice,
+    plus symmetry / diagonal / value-set properties on the whole matrix."""
+    from dynaalign_amd import synth
+    res, off = synth.uniform_peptides(10000, 20, seed=7)
+    seqs = synth.to_strings(res, off)
+    M = np.asarray(da.similarityMH(seqs, 4, 500, seed=12345))
+    assert M.shape == (10000, 10000)
+    assert np.array_equal(M, M.T)
+    assert np.all(np.diag(M) == 1.0)
+    cnt = M * 500
+    assert np.array_equal(cnt, np.round(cnt)) and cnt.min() >= 0 and cnt.max() <= 500
+    seeds = da.hash_family_seeds(12345, 500)
+    sig = O.signatures(seqs, 4, 500, seeds)
+    assert np.array_equal(da.minhash_signatures(seqs, 4, 500, seed=12345), sig)   # bit-exact signatures
+    for r0 in (0, 4993, 9900):
+        want = O.mh_counts(sig, r0, r0 + 100).astype(np.float64) / 500
+        assert_same_f64(M[r0:r0 + 100], want)
+    # checksum of the WHOLE count matrix that never walks the pair loop:
+    #   sum_ij matches(i,j) = sum_h sum_v (number of sequences whose sig[.,h] == v)^2
+    total = 0
+    for h in range(500):
+        _, c = np.unique(sig[:, h], return_counts=True)
+        total += int((c.astype(np.int64) ** 2).sum())
+    sub = da.mh_counts(seqs, 4, 500, seed=12345)
+    assert sub.shape == (10000, 10000)
+    assert int(sub.astype(np.int64).sum()) == total
+    assert np.array_equal(sub.astype(np.float64) / 500, M)
+
+
+def test_nw_10k_sampled_rows(da):
+    """config 3: 10k synthetic 20-mers, BLOSUM62 full N x N: oracle compare on row slices
+    (the CPU oracle needs ~16 us/pair) + symmetry/diagonal/range properties."""
+    from dynaalign_amd import synth
+    res, off = synth.uniform_peptides(10000, 20, seed=7)
+    seqs = synth.to_strings(res, off)
+    W = np.asarray(da.similarityNW(seqs))
+    assert W.shape == (10000, 10000)
+    assert np.array_equal(W, W.T) and np.all(np.diag(W) == 1.0)
+    assert W.min() >= 0.0 and W.max() <= 1.0
+    for r0 in (0, 5000, 9990):
+        rc, mt, ln, sc, _ = O.nw_rows(seqs, r0, r0 + 10)
+        assert rc == 0
+        assert_same_f64(W[r0:r0 + 10], mt / ln.astype(np.float64))
