@@ -119,6 +119,7 @@ def main():
     ds = device.DeviceSequences(res, off, "cuda")
     d_seeds = torch.from_numpy(seeds.view(np.int32).copy()).cuda()
     sig = torch.empty((n, device.sig_ld(n_hash)), dtype=torch.int32, device="cuda")
+    planes = torch.empty_like(sig)
 
     pairs_mh = n * (n - 1) // 2            # unordered pairs, diagonal excluded (src/minHash.cpp:164)
     pairs_nw = n * (n + 1) // 2            # the reference computes the NW diagonal (src/pairwiseSeqAlign.cpp:342)
@@ -132,9 +133,9 @@ def main():
         def step(record=False):
             e0, e1, e2 = ev(), ev(), ev()
             e0.record()
-            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig)
+            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes)
             e1.record()
-            device.mh_compare(sig, n, n_hash, 0, n, True, _capi.DA_OUT_F64, out=out)
+            device.mh_compare(planes, n, n_hash, 0, n, True, _capi.DA_OUT_F64, out=out)
             e2.record()
             if record:
                 return e0, e1, e2
@@ -146,9 +147,9 @@ def main():
         def step(record=False):
             e0, e1, e2 = ev(), ev(), ev()
             e0.record()
-            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig)   # every rank rebuilds all signatures (2 MB in)
+            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes)   # every rank rebuilds all signatures (2 MB in)
             e1.record()
-            sharding.mh_sharded_step(plan, work, sig, n_hash, out)
+            sharding.mh_sharded_step(plan, work, planes, n_hash, out)
             e2.record()
             if record:
                 return e0, e1, e2

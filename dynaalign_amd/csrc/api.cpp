@@ -192,32 +192,36 @@ int da_matrix_id(const char *matrix_name) {
 
 int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n,
                               int64_t total_residues, int64_t max_len, int k, int n_hash,
-                              const uint32_t *d_seeds, uint32_t *d_sig, int64_t ld_sig, void *stream) {
+                              const uint32_t *d_seeds, uint32_t *d_sig, int64_t ld_sig,
+                              uint32_t *d_planes, int64_t ld_planes, void *stream) {
   (void)total_residues; (void)max_len;
   int rc = validate_mh(n, k, n_hash);
   if (rc != DA_OK) return rc;
   if (!d_residues || !d_offsets || !d_seeds || !d_sig) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
   if (ld_sig < n_hash) return fail(DA_ERR_BAD_ARG, "ld_sig (%lld) < n_hash (%d)", (long long)ld_sig, n_hash);
-  return launch_minhash_signatures(d_residues, d_offsets, n, k, n_hash, d_seeds, d_sig, ld_sig,
-                                   static_cast<hipStream_t>(stream));
+  if (d_planes && (ld_planes < sig_ld_for(n_hash) || (ld_planes & 31)))
+    return fail(DA_ERR_BAD_ARG, "ld_planes must be a multiple of 32 and >= da_sig_ld(n_hash) = %lld",
+                (long long)sig_ld_for(n_hash));
+  return launch_minhash_signatures(d_residues, d_offsets, n, k, n_hash, d_seeds, d_sig, ld_sig, d_planes,
+                                   ld_planes, static_cast<hipStream_t>(stream));
 }
 
-int da_dev_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, int symmetric, int kind, void *d_out,
                       int64_t ld, void *stream) {
   if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
   if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
-  if (!d_sig || !d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if (!d_planes || !d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
   if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(DA_ERR_BAD_ARG, "bad row range");
   if (symmetric && (row_begin != 0 || row_end != n))
     return fail(DA_ERR_BAD_ARG, "symmetric mode needs the full row range");
   if (ld < n) return fail(DA_ERR_BAD_ARG, "ld (%lld) < n (%lld)", (long long)ld, (long long)n);
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "bad output kind");
-  if (kind == DA_OUT_COMPACT && n_hash > 65535)
-    return fail(DA_ERR_UNSUPPORTED, "uint16 match counts need n_hash <= 65535 (got %d)", n_hash);
-  if ((ld_sig & 3) || (reinterpret_cast<uintptr_t>(d_sig) & 15) || ld_sig < n_hash)
-    return fail(DA_ERR_BAD_ARG, "signature matrix must be 16-byte aligned with ld_sig %% 4 == 0 and ld_sig >= n_hash");
-  return launch_mh_compare(d_sig, ld_sig, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
+  if (n_hash > 65535)
+    return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
+  if ((ld_planes & 31) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < sig_ld_for(n_hash))
+    return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 32, >= da_sig_ld(n_hash)");
+  return launch_mh_compare(d_planes, ld_planes, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
                            static_cast<hipStream_t>(stream));
 }
 
@@ -270,7 +274,7 @@ int da_minhash_signatures(const uint8_t *residues, const int64_t *offsets, int64
   DevBuf sig;
   if ((rc = sig.alloc((size_t)n * ld * sizeof(uint32_t))) != DA_OK) return rc;
   rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
-                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), ld, nullptr);
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), ld, nullptr, 0, nullptr);
   if (rc != DA_OK) return rc;
   DA_HIP_TRY(hipMemcpy2D(sig_out, (size_t)n_hash * 4, sig.p, (size_t)ld * 4, (size_t)n_hash * 4, (size_t)n,
                          hipMemcpyDeviceToHost));
@@ -283,18 +287,20 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   if (rc != DA_OK) return rc;
   if (!residues || !seeds || !out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
   if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(DA_ERR_BAD_ARG, "bad row range");
-  if (kind == DA_OUT_COMPACT && n_hash > 65535)
-    return fail(DA_ERR_UNSUPPORTED, "uint16 match counts need n_hash <= 65535 (got %d)", n_hash);
+  if (n_hash > 65535)
+    return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
   int64_t total, max_len;
   if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
   if ((rc = require_device()) != DA_OK) return rc;
   DeviceInput in;
   if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
   const int64_t lds = sig_ld_for(n_hash);
-  DevBuf sig;
+  DevBuf sig, planes;
   if ((rc = sig.alloc((size_t)n * lds * sizeof(uint32_t))) != DA_OK) return rc;
+  if ((rc = planes.alloc((size_t)n * lds * sizeof(uint32_t))) != DA_OK) return rc;
   rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
-                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, nullptr);
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, planes.as<uint32_t>(), lds,
+                                 nullptr);
   if (rc != DA_OK) return rc;
   const size_t esz = kind == DA_OUT_F64 ? sizeof(double) : sizeof(uint16_t);
   const int64_t rows_total = row_end - row_begin;
@@ -303,14 +309,14 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   DevBuf dout;
   if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * esz)) != DA_OK) return rc;
   if (whole) {  // everything fits: compare only the upper triangle, store both halves
-    rc = launch_mh_compare(sig.as<uint32_t>(), lds, n, n_hash, 0, n, true, kind, dout.p, n, nullptr);
+    rc = launch_mh_compare(planes.as<uint32_t>(), lds, n, n_hash, 0, n, true, kind, dout.p, n, nullptr);
     if (rc != DA_OK) return rc;
     DA_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * (size_t)n * esz, hipMemcpyDeviceToHost));
     return DA_OK;
   }
   for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
     const int64_t r1 = std::min(row_end, r0 + blk);
-    rc = launch_mh_compare(sig.as<uint32_t>(), lds, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr);
+    rc = launch_mh_compare(planes.as<uint32_t>(), lds, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr);
     if (rc != DA_OK) return rc;
     DA_HIP_TRY(hipMemcpy(static_cast<char *>(out) + (size_t)(r0 - row_begin) * (size_t)n * esz, dout.p,
                          (size_t)(r1 - r0) * (size_t)n * esz, hipMemcpyDeviceToHost));

@@ -34,8 +34,9 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // asynchronous on `stream`; argument checking is done by the C-ABI layer.
 int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n,
                               int k, int n_hash, const uint32_t *d_seeds, uint32_t *d_sig,
-                              int64_t ld_sig, hipStream_t stream);
-int launch_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+                              int64_t ld_sig, uint32_t *d_planes, int64_t ld_planes,
+                              hipStream_t stream);
+int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
                       void *d_out, int64_t ld, hipStream_t stream);
 int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,

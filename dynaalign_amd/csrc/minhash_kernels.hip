@@ -59,7 +59,8 @@ constexpr int K1_CHUNK = 1024;  // window positions staged per pass
 template <bool K_IS_4>
 __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
     const uint8_t *__restrict__ residues, const int64_t *__restrict__ offsets, int k, int n_hash,
-    const uint32_t *__restrict__ seeds, uint32_t *__restrict__ sig, int64_t ld_sig) {
+    const uint32_t *__restrict__ seeds, uint32_t *__restrict__ sig, int64_t ld_sig,
+    uint32_t *__restrict__ planes, int64_t ld_planes) {
   extern __shared__ uint32_t lds_k1[];
   const int64_t seq = blockIdx.x;
   const int64_t beg = offsets[seq];
@@ -72,10 +73,8 @@ __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
   uint32_t *row = sig + seq * ld_sig;
   const uint8_t *s = residues + beg;
 
-  if (nwin == 0) {  // identity of min: UINT32_MAX (src/minHash.cpp:140)
+  if (nwin == 0)  // identity of min: UINT32_MAX (src/minHash.cpp:140)
     for (int h = threadIdx.x; h < n_hash; h += K1_THREADS) row[h] = 0xffffffffu;
-    return;
-  }
   for (int64_t c0 = 0; c0 < nwin; c0 += K1_CHUNK) {
     const int cw = (int)((nwin - c0 < K1_CHUNK) ? (nwin - c0) : K1_CHUNK);
     const int need = cw + k - 1;  // byte positions c0 .. c0+need-1 are inside the sequence
@@ -116,14 +115,51 @@ __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
       row[h] = best;
     }
   }
+
+  // ---- bit-plane copy for the compare kernel: every group of 32 hash functions
+  // g is stored as 32 words, word p holding bit p of sig[32g+0..31] (a 32x32 bit
+  // transpose done with wave ballots: lane l of a wave holds h = base + l, so the
+  // low/high halves of a 64-bit ballot are plane p of two adjacent groups).
+  // Hash functions >= n_hash contribute 0 bits in every sequence, i.e. "equal".
+  if (planes) {
+    uint32_t *prow = planes + seq * ld_planes;
+    const int lane = threadIdx.x & 63;
+    for (int h0 = 0; h0 < ld_planes; h0 += K1_THREADS) {
+      const int hw = h0 + (threadIdx.x & ~63);       // first h of this wave
+      if (hw >= ld_planes) break;                    // wave-uniform
+      const int h = hw + lane;
+      const uint32_t v = (h < n_hash) ? row[h] : 0u;  // own earlier store (same thread wrote row[h])
+      uint32_t w = 0;
+#pragma unroll
+      for (int p = 0; p < 32; ++p) {
+        const unsigned long long m = __ballot((v >> p) & 1u);
+        const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+        w = ((lane & 31) == p) ? half : w;
+      }
+      if (h < ld_planes) prow[h] = w;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- compare --
+// Bit-sliced equality.  On gfx950 integer compares, v_cndmask, v_addc and
+// v_bcnt issue at half rate (16 lanes/clk/SIMD) while v_bitop3_b32 -- any
+// 3-input boolean function -- issues at the full 32 lanes/clk (measured:
+// profiles/r01_ubench_inst_rate.txt).  So instead of "compare two u32, add the
+// carry" (2 half-rate ops per hash function) the kernel works on the 32x32
+// bit-transposed signatures K1 emits: for a group of 32 hash functions,
+//     d = OR over the 32 bit planes p of (A_p XOR B_p)
+// has bit t set iff the two sequences DIFFER at hash function 32g+t, and costs
+// one full-rate  v_bitop3 d, d, a, b  (d | (a ^ b))  per plane; one v_bcnt per
+// group then adds popcount(d) to the pair's mismatch count.  That is ~1.03
+// instructions per hash function instead of 2, all but 1/33 of them full rate.
+// matches = n_hash - mismatches; padding hash functions are all-zero planes on
+// both sides and never count as mismatches.
+//
 // Pair-space tile of 128 x 128 per 256-thread workgroup; each lane keeps an
-// 8 x 8 block of match counters in registers (64 VGPRs).  Signature slices of
-// HC = 32 hash functions are staged through LDS; per 4 hash functions a lane
-// issues 8 + 8 ds_read_b128 and 256 compare+add pairs, so the kernel is bound
-// by integer VALU issue (2 lane-ops per compare), not by LDS or HBM.
+// 8 x 8 block of pairs in registers (64 OR-accumulators + 64 mismatch counters).
+// Plane words of HC = 32 hash functions (one group, 128 B per sequence) are
+// staged through LDS per step.
 constexpr int K2_TILE = 128;
 constexpr int K2_HC = 32;            // hash functions per LDS stage
 constexpr int K2_SEGS = K2_HC / 4;   // 16-byte segments per row per stage
@@ -139,6 +175,12 @@ __device__ __forceinline__ int k2_slot(int r) { return (((r >> 5) * 2 + (r & 1))
 // slot, 8 segments) and the compute reads (<= 8 consecutive slots, one
 // segment) are conflict-free.
 __device__ __forceinline__ int k2_unit(int slot, int seg) { return slot * K2_SEGS + (seg ^ (slot & 7)); }
+
+// d | (a ^ b) as ONE full-rate v_bitop3_b32 (truth table over S0=0xF0,S1=0xCC,S2=0xAA:
+// 0xF0 | (0xCC ^ 0xAA) = 0xF6).  Left to itself hipcc picks v_xor + v_or3 (half rate).
+__device__ __forceinline__ uint32_t or_xor(uint32_t d, uint32_t a, uint32_t b) {
+  return __builtin_amdgcn_bitop3_b32(d, a, b, 0xF6);
+}
 
 struct TileId { int ti, tj; bool valid; };
 
@@ -205,17 +247,25 @@ __host__ __device__ inline int64_t count_tiles(int TR, int T, bool symmetric) {
   return (int64_t)T * (T + 1) / 2;
 }
 
+// Inverse of k2_slot: which tile row lives in LDS slot s.
+__device__ __forceinline__ int k2_row_of_slot(int s) { return ((s >> 5) << 5) + ((s & 15) << 1) + ((s >> 4) & 1); }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
 template <bool SYM, bool F64>
 __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
-    const uint32_t *__restrict__ sig, int64_t ld_sig, int64_t n, int n_hash, int64_t row_begin,
+    const uint32_t *__restrict__ planes, int64_t ld_p, int64_t n, int n_hash, int64_t row_begin,
     int64_t row_end, void *__restrict__ out_v, int64_t ld, int64_t ntiles, int64_t per_xcd) {
-  __shared__ __attribute__((aligned(16))) uint4 lds_ab[2 * K2_TILE * K2_SEGS];  // 32 KiB: a-rows then b-rows
+  // two stages of {128 a-rows, 128 b-rows} x 8 segments x 16 B = 2 x 32 KiB
+  constexpr int STAGE_UNITS = 2 * K2_TILE * K2_SEGS;
+  __shared__ __attribute__((aligned(16))) uint4 lds_ab[2 * STAGE_UNITS];
 
   // ---- which tile: blocks b and b+8 share an XCD, so give XCD x the
   // contiguous id range [x*per_xcd, (x+1)*per_xcd) (speed only).
   const int64_t bid = blockIdx.x;
   const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
-  if ((bid >> 3) >= per_xcd || L >= ntiles) return;
+  if (L >= ntiles) return;
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
   const int TR = (int)((row_end - row_begin + K2_TILE - 1) / K2_TILE);
   const TileId tid2 = decode_tile(L, TR, T, SYM);
@@ -228,70 +278,72 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
   const int tx = ((wave & 1) << 3) + (lane & 7);   // column coordinate 0..15
   const int ty = ((wave >> 1) << 3) + (lane >> 3); // row coordinate 0..15
 
-  // ---- staging assignment: 8 lanes fetch one signature row slice (8 x 16 B
-  // = 128 B contiguous); 256 threads cover 32 rows per pass, 8 passes cover
-  // the 128 a-rows + 128 b-rows.
-  const int st_seg = tid & 7;
-  const int st_row = tid >> 3;  // 0..31
-  uint4 stage[8];
-  auto fetch = [&](int h0) {
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4): one wave instruction
+  // lands 64 x 16 B = 8 slots x 128 B contiguously in LDS, no VGPRs, no
+  // ds_write.  LDS is written linearly (base + lane*16), so the XOR swizzle is
+  // applied on the SOURCE side: lane l of instruction q fills physical
+  // position (l & 7) of slot (q*8 + l>>3) with logical segment (l&7)^(slot&7).
+  // A wave issues 8 instructions per stage (4 waves x 8 x 1 KiB = 32 KiB).
+  const uint32_t *src[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int r = st_row + 32 * (p & 3);           // tile row/col index 0..127
-      const bool is_b = p >= 4;
-      const int64_t g = (is_b ? J0 : I0) + r;        // global sequence index
-      const int h = h0 + st_seg * 4;
-      const uint32_t pad = is_b ? 0xffffffffu : 0u;  // a-pad != b-pad: padding never matches
-      uint4 v = make_uint4(pad, pad, pad, pad);
-      if (g < n && h < n_hash) {  // rows are 16-byte aligned and ld_sig % 4 == 0: the vector load stays inside the row
-        v = *reinterpret_cast<const uint4 *>(sig + g * ld_sig + h);
-        if (h + 1 >= n_hash) v.y = pad;
-        if (h + 2 >= n_hash) v.z = pad;
-        if (h + 3 >= n_hash) v.w = pad;
-      }
-      stage[p] = v;
-    }
-  };
-  auto commit = [&]() {
+  for (int q = 0; q < 8; ++q) {
+    const int s = (wave * 8 + q) * 8 + (lane >> 3);  // slot 0..255 (a: 0..127, b: 128..255)
+    const int sl = s & 127;
+    const int seg = (lane & 7) ^ (sl & 7);
+    int64_t g = ((s < 128) ? I0 : J0) + k2_row_of_slot(sl);
+    if (g > n - 1) g = n - 1;                         // rows past the end: any valid row, never stored
+    src[q] = planes + g * ld_p + seg * 4;
+  }
+  auto issue = [&](int ch, int buf) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int r = st_row + 32 * (p & 3);
-      const int base = (p >= 4) ? K2_TILE * K2_SEGS : 0;
-      lds_ab[base + k2_unit(k2_slot(r), st_seg)] = stage[p];
+    for (int q = 0; q < 8; ++q) {
+      uint4 *dst = lds_ab + buf * STAGE_UNITS + (wave * 8 + q) * 64;  // wave-uniform base
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(src[q] + ch * K2_HC), (lds_void_t *)dst, 16, 0, 0);
     }
   };
 
-  uint32_t acc[8][8];
+  uint32_t mis[8][4];  // mismatch counters, two 16-bit counters per register (columns 2j, 2j+1)
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[r][c] = 0;
+    for (int c = 0; c < 4; ++c) mis[r][c] = 0;
 
-  const int nchunk = (n_hash + K2_HC - 1) / K2_HC;
-  fetch(0);
+  const int nchunk = (n_hash + K2_HC - 1) / K2_HC;  // one chunk = one group of 32 hash functions = 32 planes
+  issue(0, 0);
   for (int ch = 0; ch < nchunk; ++ch) {
-    __syncthreads();  // previous chunk's reads are done
-    commit();
+    // the barrier's fence waits for this wave's DMA (vmcnt(0)); after it every wave's
+    // share of stage ch has landed and nobody still reads the other buffer
     __syncthreads();
-    if (ch + 1 < nchunk) fetch((ch + 1) * K2_HC);  // global loads fly under the compare loop
-#pragma unroll 1
-    for (int seg = 0; seg < K2_SEGS; ++seg) {
+    if (ch + 1 < nchunk) issue(ch + 1, (ch + 1) & 1);
+    const uint4 *A = lds_ab + (ch & 1) * STAGE_UNITS;
+    const uint4 *B = A + K2_TILE * K2_SEGS;
+    uint32_t d[8][8];  // d |= a_p ^ b_p over the 32 planes
+#pragma unroll
+    for (int seg = 0; seg < K2_SEGS; ++seg) {  // 4 planes per 16-byte segment
       uint4 a[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) a[r] = lds_ab[k2_unit(r * 16 + ty, seg)];
+      for (int r = 0; r < 8; ++r) a[r] = A[k2_unit(r * 16 + ty, seg)];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const uint4 b = lds_ab[K2_TILE * K2_SEGS + k2_unit(c * 16 + tx, seg)];
+        const uint4 b = B[k2_unit(c * 16 + tx, seg)];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          acc[r][c] += (a[r].x == b.x);
-          acc[r][c] += (a[r].y == b.y);
-          acc[r][c] += (a[r].z == b.z);
-          acc[r][c] += (a[r].w == b.w);
+          uint32_t v = (seg == 0) ? (a[r].x ^ b.x) : or_xor(d[r][c], a[r].x, b.x);
+          v = or_xor(v, a[r].y, b.y);
+          v = or_xor(v, a[r].z, b.z);
+          d[r][c] = or_xor(v, a[r].w, b.w);
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        mis[r][c] += (uint32_t)__builtin_popcount(d[r][2 * c]) + ((uint32_t)__builtin_popcount(d[r][2 * c + 1]) << 16);
   }
+  auto matches = [&](int r, int c) -> uint32_t {  // reference src/minHash.cpp:168-173
+    return (uint32_t)n_hash - ((mis[r][c >> 1] >> ((c & 1) * 16)) & 0xffffu);
+  };
 
   // ---- epilogue.  count -> double through a table built with the same
   // IEEE divide the reference does ((double)matches / n_hash,
@@ -308,7 +360,7 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
     return use_table ? ratio[c] : (double)c / (double)n_hash;
   };
 
-  // lane's rows: 32*g + 2*ty + e  <-> acc index r = 2*g + e ; cols likewise.
+  // lane's rows: 32*g + 2*ty + e  <-> index r = 2*g + e ; cols likewise.
   if (F64) {
     double *out = reinterpret_cast<double *>(out_v);
     const bool vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -320,7 +372,7 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t gj = J0 + 32 * g + 2 * tx;
-        const double v0 = widen(acc[r][2 * g]), v1 = widen(acc[r][2 * g + 1]);
+        const double v0 = widen(matches(r, 2 * g)), v1 = widen(matches(r, 2 * g + 1));
         if (vec_ok && gj + 1 < n) {
           *reinterpret_cast<double2 *>(orow + gj) = make_double2(v0, v1);
         } else {
@@ -338,7 +390,7 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int64_t gi = I0 + 32 * g + 2 * ty;
-          const double v0 = widen(acc[2 * g][c]), v1 = widen(acc[2 * g + 1][c]);
+          const double v0 = widen(matches(2 * g, c)), v1 = widen(matches(2 * g + 1, c));
           if (vec_ok && gi + 1 < n) {
             *reinterpret_cast<double2 *>(orow + gi) = make_double2(v0, v1);
           } else {
@@ -358,8 +410,8 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t gj = J0 + 32 * g + 2 * tx;
-        if (gj < n) orow[gj] = (uint16_t)acc[r][2 * g];
-        if (gj + 1 < n) orow[gj + 1] = (uint16_t)acc[r][2 * g + 1];
+        if (gj < n) orow[gj] = (uint16_t)matches(r, 2 * g);
+        if (gj + 1 < n) orow[gj + 1] = (uint16_t)matches(r, 2 * g + 1);
       }
     }
     if (SYM && tid2.ti != tid2.tj) {
@@ -371,8 +423,8 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int64_t gi = I0 + 32 * g + 2 * ty;
-          if (gi < n) orow[gi] = (uint16_t)acc[2 * g][c];
-          if (gi + 1 < n) orow[gi + 1] = (uint16_t)acc[2 * g + 1][c];
+          if (gi < n) orow[gi] = (uint16_t)matches(2 * g, c);
+          if (gi + 1 < n) orow[gi + 1] = (uint16_t)matches(2 * g + 1, c);
         }
       }
     }
@@ -410,16 +462,17 @@ __global__ __launch_bounds__(256) void k_widen(const uint16_t *__restrict__ in, 
 
 int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n, int k,
                               int n_hash, const uint32_t *d_seeds, uint32_t *d_sig,
-                              int64_t ld_sig, hipStream_t stream) {
+                              int64_t ld_sig, uint32_t *d_planes, int64_t ld_planes,
+                              hipStream_t stream) {
   if (n <= 0) return DA_OK;
   if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "more than 2^31-1 sequences");
   const size_t lds = 2 * (size_t)(K1_CHUNK + k) * sizeof(uint32_t);
   if (lds > 64 * 1024) return fail(DA_ERR_UNSUPPORTED, "k = %d is larger than the signature kernel supports (k <= 7168)", k);
   dim3 grid((unsigned)n), block(K1_THREADS);
   if (k == 4)
-    hipLaunchKernelGGL(k_minhash_signatures<true>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig);
+    hipLaunchKernelGGL(k_minhash_signatures<true>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig, d_planes, ld_planes);
   else
-    hipLaunchKernelGGL(k_minhash_signatures<false>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig);
+    hipLaunchKernelGGL(k_minhash_signatures<false>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig, d_planes, ld_planes);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

@@ -41,9 +41,10 @@ def sig_ld(n_hash):
     return int(_capi.load().da_sig_ld(int(n_hash)))
 
 
-def minhash_signatures(ds, k, n_hash, seeds, out=None):
-    """K1.  Returns an int32 tensor (n, sig_ld(n_hash)) holding the uint32 signatures
-    in columns [0, n_hash)."""
+def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=True):
+    """K1.  Returns (sig, planes): int32 tensors (n, sig_ld(n_hash)).  `sig` holds the uint32
+    signatures in columns [0, n_hash); `planes` the same data bit-transposed in groups of 32
+    hash functions -- the operand of mh_compare (None if want_planes is False)."""
     lib = _capi.load()
     if not torch.is_tensor(seeds):
         seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32).copy()).to(ds.residues.device)
@@ -51,10 +52,13 @@ def minhash_signatures(ds, k, n_hash, seeds, out=None):
     ld = sig_ld(n_hash) if n_hash > 0 else 32
     if out is None:
         out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
+    if planes is None and want_planes:
+        planes = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
     _capi.check(lib.da_dev_minhash_signatures(ds.residues.data_ptr(), ds.offsets.data_ptr(), ds.n, ds.total,
                                               ds.max_len, int(k), int(n_hash), seeds.data_ptr(), out.data_ptr(),
-                                              out.stride(0), _stream()))
-    return out
+                                              out.stride(0), None if planes is None else planes.data_ptr(),
+                                              0 if planes is None else planes.stride(0), _stream()))
+    return out, planes
 
 
 def _alloc_out(rows, n, kind, device, out):
@@ -65,10 +69,10 @@ def _alloc_out(rows, n, kind, device, out):
 
 
 def mh_compare(sig, n, n_hash, row_begin=0, row_end=None, symmetric=None, kind=DA_OUT_F64, out=None):
-    """K2.  Rows [row_begin,row_end) of the n x n similarity (float64) or match-count
-    (uint16 in an int16 tensor) matrix."""
+    """K2.  `sig` is the bit-plane tensor from minhash_signatures.  Rows [row_begin,row_end) of the
+    n x n similarity (float64) or match-count (uint16 in an int16 tensor) matrix."""
     lib = _capi.load()
-    _require_cuda(sig, "signatures")
+    _require_cuda(sig, "bit planes")
     row_end = n if row_end is None else row_end
     if symmetric is None:
         symmetric = (row_begin == 0 and row_end == n)

@@ -119,19 +119,26 @@ int da_nw_pairs(const uint8_t *residues, const int64_t *offsets, int64_t n,
 
 /* ---- device-pointer entry points (bench / multi-GPU sharding) ------------ */
 
-/* Leading dimension (in uint32 elements) the library uses for signature
- * matrices: n_hash rounded up to a multiple of 32, so that every row starts
- * 16-byte aligned for the compare kernel's vector loads. */
+/* Leading dimension (in uint32 elements) the library uses for signature and
+ * bit-plane matrices: n_hash rounded up to a multiple of 32. */
 int64_t da_sig_ld(int n_hash);
 
-/* K1: signature build.  d_sig holds n rows of ld_sig (>= n_hash) uint32;
- * columns [n_hash, ld_sig) are not written. */
+/* K1: signature build.
+ *   d_sig    : n rows of ld_sig (>= n_hash) uint32 -- the signatures themselves
+ *              (src/minHash.cpp:140-157); columns [n_hash, ld_sig) not written.
+ *   d_planes : optional (NULL to skip) n rows of ld_planes uint32, ld_planes a
+ *              multiple of 32 and >= da_sig_ld(n_hash): the same signatures
+ *              bit-transposed in groups of 32 hash functions (word 32g+p = bit p
+ *              of sig[32g .. 32g+31]; hash functions >= n_hash read as 0).  This
+ *              is the operand of the compare kernel. */
 int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n,
                               int64_t total_residues, int64_t max_len,
                               int k, int n_hash, const uint32_t *d_seeds,
-                              uint32_t *d_sig, int64_t ld_sig, void *stream);
+                              uint32_t *d_sig, int64_t ld_sig,
+                              uint32_t *d_planes, int64_t ld_planes, void *stream);
 
-/* K2: all-pairs signature compare.
+/* K2: all-pairs signature compare (bit-sliced: OR over planes of a XOR b, then
+ * popcount; matches = n_hash - mismatches).
  * Computes rows [row_begin,row_end) of the n x n result into d_out, which
  * holds (row_end-row_begin) rows of leading dimension ld (>= n) elements.
  *   symmetric != 0 : requires row_begin == 0, row_end == n; only tiles on or
@@ -139,8 +146,8 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
  *                    (direct + mirrored), like src/minHash.cpp:175-176.
  *   symmetric == 0 : every (i,j) of the row block is compared (row-sharding).
  * kind selects double or uint16 counts.  Diagonal = 1.0 / n_hash.
- * d_sig must be 16-byte aligned with ld_sig % 4 == 0 (use da_sig_ld). */
-int da_dev_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+ * d_planes: 16-byte aligned bit-plane matrix from da_dev_minhash_signatures. */
+int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, int symmetric,
                       int kind, void *d_out, int64_t ld, void *stream);
 
