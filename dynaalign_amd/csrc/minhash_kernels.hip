@@ -161,8 +161,10 @@ __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
 // Plane words of HC = 32 hash functions (one group, 128 B per sequence) are
 // staged through LDS per step.
 constexpr int K2_TILE = 128;
-constexpr int K2_HC = 32;            // hash functions per LDS stage
-constexpr int K2_SEGS = K2_HC / 4;   // 16-byte segments per row per stage
+constexpr int K2_GROUP = 32;         // hash functions per bit-plane group (= planes per group)
+constexpr int K2_SP = 16;            // planes per LDS stage (half a group)
+constexpr int K2_SEGS = K2_SP / 4;   // 16-byte segments per row per stage
+constexpr int K2_NSTAGE = 3;         // LDS ring depth
 constexpr int K2_BAND = 8;           // tile rows per L2-resident band
 constexpr int K2_THREADS = 256;
 
@@ -170,11 +172,12 @@ constexpr int K2_THREADS = 256;
 // LDS slot of tile row r:  ((r>>5)*2 + (r&1))*16 + ((r&31)>>1)  -- makes the
 // 16 lanes of a ds_read_b128 group hit consecutive slots.
 __device__ __forceinline__ int k2_slot(int r) { return (((r >> 5) * 2 + (r & 1)) << 4) + ((r & 31) >> 1); }
-// 16-byte unit index inside one operand buffer; XOR swizzle spreads the 8
-// segments of a slot over banks so both the staging writes (8 lanes = one
-// slot, 8 segments) and the compute reads (<= 8 consecutive slots, one
-// segment) are conflict-free.
-__device__ __forceinline__ int k2_unit(int slot, int seg) { return slot * K2_SEGS + (seg ^ (slot & 7)); }
+// Inverse: which tile row lives in LDS slot s.
+__device__ __forceinline__ int k2_row_of_slot(int s) { return ((s >> 5) << 5) + ((s & 15) << 1) + ((s >> 4) & 1); }
+// 16-byte unit index inside one operand buffer (4 segments per slot per stage).
+// The XOR swizzle makes a ds_read_b128 group (<= 8 consecutive slots, one
+// segment) hit 8 different 16-byte bank groups.
+__device__ __forceinline__ int k2_unit(int slot, int seg) { return slot * K2_SEGS + (seg ^ ((slot >> 2) & 3)); }
 
 // d | (a ^ b) as ONE full-rate v_bitop3_b32 (truth table over S0=0xF0,S1=0xCC,S2=0xAA:
 // 0xF0 | (0xCC ^ 0xAA) = 0xF6).  Left to itself hipcc picks v_xor + v_or3 (half rate).
@@ -247,19 +250,16 @@ __host__ __device__ inline int64_t count_tiles(int TR, int T, bool symmetric) {
   return (int64_t)T * (T + 1) / 2;
 }
 
-// Inverse of k2_slot: which tile row lives in LDS slot s.
-__device__ __forceinline__ int k2_row_of_slot(int s) { return ((s >> 5) << 5) + ((s & 15) << 1) + ((s >> 4) & 1); }
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
 template <bool SYM, bool F64>
-__global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
+__global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const uint32_t *__restrict__ planes, int64_t ld_p, int64_t n, int n_hash, int64_t row_begin,
     int64_t row_end, void *__restrict__ out_v, int64_t ld, int64_t ntiles, int64_t per_xcd) {
-  // two stages of {128 a-rows, 128 b-rows} x 8 segments x 16 B = 2 x 32 KiB
+  // ring of 3 stages; a stage = 16 planes of {128 a-rows, 128 b-rows} = 256 x 64 B = 16 KiB
   constexpr int STAGE_UNITS = 2 * K2_TILE * K2_SEGS;
-  __shared__ __attribute__((aligned(16))) uint4 lds_ab[2 * STAGE_UNITS];
+  __shared__ __attribute__((aligned(16))) uint4 lds_ab[K2_NSTAGE * STAGE_UNITS];
 
   // ---- which tile: blocks b and b+8 share an XCD, so give XCD x the
   // contiguous id range [x*per_xcd, (x+1)*per_xcd) (speed only).
@@ -279,27 +279,26 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
   const int ty = ((wave >> 1) << 3) + (lane >> 3); // row coordinate 0..15
 
   // ---- staging by LDS-DMA (global_load_lds_dwordx4): one wave instruction
-  // lands 64 x 16 B = 8 slots x 128 B contiguously in LDS, no VGPRs, no
+  // lands 64 x 16 B = 16 slots x 64 B contiguously in LDS -- no VGPRs, no
   // ds_write.  LDS is written linearly (base + lane*16), so the XOR swizzle is
   // applied on the SOURCE side: lane l of instruction q fills physical
-  // position (l & 7) of slot (q*8 + l>>3) with logical segment (l&7)^(slot&7).
-  // A wave issues 8 instructions per stage (4 waves x 8 x 1 KiB = 32 KiB).
-  const uint32_t *src[8];
+  // position (l & 3) of slot (q*16 + l>>2) with logical segment
+  // (l&3) ^ ((slot>>2)&3).  A wave issues 4 instructions per stage.
+  const uint32_t *src[4];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int s = (wave * 8 + q) * 8 + (lane >> 3);  // slot 0..255 (a: 0..127, b: 128..255)
+  for (int q = 0; q < 4; ++q) {
+    const int s = (wave * 4 + q) * 16 + (lane >> 2);  // slot 0..255 (a: 0..127, b: 128..255)
     const int sl = s & 127;
-    const int seg = (lane & 7) ^ (sl & 7);
+    const int seg = (lane & 3) ^ ((sl >> 2) & 3);
     int64_t g = ((s < 128) ? I0 : J0) + k2_row_of_slot(sl);
-    if (g > n - 1) g = n - 1;                         // rows past the end: any valid row, never stored
+    if (g > n - 1) g = n - 1;                          // rows past the end: any valid row, never stored
     src[q] = planes + g * ld_p + seg * 4;
   }
-  auto issue = [&](int ch, int buf) {
+  auto issue = [&](int stage) {  // stage s holds planes [16 s, 16 s + 16)
+    uint4 *base = lds_ab + (stage % K2_NSTAGE) * STAGE_UNITS + wave * 4 * 64;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      uint4 *dst = lds_ab + buf * STAGE_UNITS + (wave * 8 + q) * 64;  // wave-uniform base
-      __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(src[q] + ch * K2_HC), (lds_void_t *)dst, 16, 0, 0);
-    }
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(src[q] + stage * K2_SP), (lds_void_t *)(base + q * 64), 16, 0, 0);
   };
 
   uint32_t mis[8][4];  // mismatch counters, two 16-bit counters per register (columns 2j, 2j+1)
@@ -308,38 +307,62 @@ __global__ __launch_bounds__(K2_THREADS, 2) void k_mh_compare(
 #pragma unroll
     for (int c = 0; c < 4; ++c) mis[r][c] = 0;
 
-  const int nchunk = (n_hash + K2_HC - 1) / K2_HC;  // one chunk = one group of 32 hash functions = 32 planes
-  issue(0, 0);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    // the barrier's fence waits for this wave's DMA (vmcnt(0)); after it every wave's
-    // share of stage ch has landed and nobody still reads the other buffer
-    __syncthreads();
-    if (ch + 1 < nchunk) issue(ch + 1, (ch + 1) & 1);
-    const uint4 *A = lds_ab + (ch & 1) * STAGE_UNITS;
-    const uint4 *B = A + K2_TILE * K2_SEGS;
-    uint32_t d[8][8];  // d |= a_p ^ b_p over the 32 planes
+  // lane-constant parts of the LDS read addresses (16-byte units); the r / c
+  // strides (16 slots = 64 units) fold into the ds_read immediate offset.
+  const int base_a = ty * K2_SEGS, base_b = K2_TILE * K2_SEGS + tx * K2_SEGS;
+  const int xa = (ty >> 2) & 3, xb = (tx >> 2) & 3;  // (slot >> 2) & 3 of the lane's slots
+
+  uint32_t d[8][8];  // d |= a_p ^ b_p over the 32 planes of a group
 #pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[r][c] = 0;
+  auto compute = [&](int stage) {
+    const uint4 *S = lds_ab + (stage % K2_NSTAGE) * STAGE_UNITS;
+#pragma unroll 1
     for (int seg = 0; seg < K2_SEGS; ++seg) {  // 4 planes per 16-byte segment
+      const uint4 *Sa = S + base_a + (seg ^ xa);
+      const uint4 *Sb = S + base_b + (seg ^ xb);
       uint4 a[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) a[r] = A[k2_unit(r * 16 + ty, seg)];
+      for (int r = 0; r < 8; ++r) a[r] = Sa[r * 16 * K2_SEGS];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const uint4 b = B[k2_unit(c * 16 + tx, seg)];
+        const uint4 b = Sb[c * 16 * K2_SEGS];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          uint32_t v = (seg == 0) ? (a[r].x ^ b.x) : or_xor(d[r][c], a[r].x, b.x);
+          uint32_t v = or_xor(d[r][c], a[r].x, b.x);
           v = or_xor(v, a[r].y, b.y);
           v = or_xor(v, a[r].z, b.z);
           d[r][c] = or_xor(v, a[r].w, b.w);
         }
       }
     }
+  };
+
+  const int ngroup = (n_hash + K2_GROUP - 1) / K2_GROUP;
+  const int nstage = 2 * ngroup;
+  issue(0);
+  issue(1);
+  for (int g = 0; g < ngroup; ++g) {
+    // The barrier's fence drains this wave's DMA (vmcnt(0)): stages 2g and 2g+1 have
+    // landed for every wave, and nobody still reads the buffer stage 2g+2 goes to
+    // (it was consumed as stage 2g-1, before this barrier).
+    __syncthreads();
+    if (2 * g + 2 < nstage) issue(2 * g + 2);
+    compute(2 * g);
+    __syncthreads();
+    if (2 * g + 3 < nstage) issue(2 * g + 3);
+    compute(2 * g + 1);
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         mis[r][c] += (uint32_t)__builtin_popcount(d[r][2 * c]) + ((uint32_t)__builtin_popcount(d[r][2 * c + 1]) << 16);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d[r][c] = 0;
   }
   auto matches = [&](int r, int c) -> uint32_t {  // reference src/minHash.cpp:168-173
     return (uint32_t)n_hash - ((mis[r][c >> 1] >> ((c & 1) * 16)) & 0xffffu);
