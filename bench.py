@@ -119,7 +119,7 @@ def main():
     ds = device.DeviceSequences(res, off, "cuda")
     d_seeds = torch.from_numpy(seeds.view(np.int32).copy()).cuda()
     sig = torch.empty((n, device.sig_ld(n_hash)), dtype=torch.int32, device="cuda")
-    planes = torch.empty_like(sig)
+    planes = torch.empty((n, device.planes_ld(n_hash)), dtype=torch.int32, device="cuda")
 
     pairs_mh = n * (n - 1) // 2            # unordered pairs, diagonal excluded (src/minHash.cpp:164)
     pairs_nw = n * (n + 1) // 2            # the reference computes the NW diagonal (src/pairwiseSeqAlign.cpp:342)

@@ -35,6 +35,7 @@ SIGNATURES = {
     "da_similarity_nw": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _vp]),
     "da_nw_pairs": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _i64, _i64, _vp, _vp, _vp]),
     "da_sig_ld": (_i64, [_i32]),
+    "da_planes_ld": (_i64, [_i32]),
     "da_dev_minhash_signatures": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
     "da_dev_mh_compare": (_i32, [_vp, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),

@@ -199,9 +199,9 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
   if (rc != DA_OK) return rc;
   if (!d_residues || !d_offsets || !d_seeds || !d_sig) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
   if (ld_sig < n_hash) return fail(DA_ERR_BAD_ARG, "ld_sig (%lld) < n_hash (%d)", (long long)ld_sig, n_hash);
-  if (d_planes && (ld_planes < sig_ld_for(n_hash) || (ld_planes & 31)))
-    return fail(DA_ERR_BAD_ARG, "ld_planes must be a multiple of 32 and >= da_sig_ld(n_hash) = %lld",
-                (long long)sig_ld_for(n_hash));
+  if (d_planes && (ld_planes < 2 * sig_ld_for(n_hash) || (ld_planes & 63)))
+    return fail(DA_ERR_BAD_ARG, "ld_planes must be a multiple of 64 and >= da_planes_ld(n_hash) = %lld",
+                (long long)(2 * sig_ld_for(n_hash)));
   return launch_minhash_signatures(d_residues, d_offsets, n, k, n_hash, d_seeds, d_sig, ld_sig, d_planes,
                                    ld_planes, static_cast<hipStream_t>(stream));
 }
@@ -219,8 +219,8 @@ int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "bad output kind");
   if (n_hash > 65535)
     return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
-  if ((ld_planes & 31) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < sig_ld_for(n_hash))
-    return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 32, >= da_sig_ld(n_hash)");
+  if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
+    return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
   return launch_mh_compare(d_planes, ld_planes, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
                            static_cast<hipStream_t>(stream));
 }
@@ -257,6 +257,7 @@ int da_dev_widen(const uint16_t *d_in, double *d_out, int64_t count, int is_nw, 
 }
 
 int64_t da_sig_ld(int n_hash) { return sig_ld_for(n_hash); }
+int64_t da_planes_ld(int n_hash) { return 2 * sig_ld_for(n_hash); }
 
 // -------------------------------------------------------------- host entry
 
@@ -297,9 +298,10 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   const int64_t lds = sig_ld_for(n_hash);
   DevBuf sig, planes;
   if ((rc = sig.alloc((size_t)n * lds * sizeof(uint32_t))) != DA_OK) return rc;
-  if ((rc = planes.alloc((size_t)n * lds * sizeof(uint32_t))) != DA_OK) return rc;
+  const int64_t ldp = 2 * lds;
+  if ((rc = planes.alloc((size_t)n * ldp * sizeof(uint32_t))) != DA_OK) return rc;
   rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
-                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, planes.as<uint32_t>(), lds,
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, planes.as<uint32_t>(), ldp,
                                  nullptr);
   if (rc != DA_OK) return rc;
   const size_t esz = kind == DA_OUT_F64 ? sizeof(double) : sizeof(uint16_t);
@@ -309,14 +311,14 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   DevBuf dout;
   if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * esz)) != DA_OK) return rc;
   if (whole) {  // everything fits: compare only the upper triangle, store both halves
-    rc = launch_mh_compare(planes.as<uint32_t>(), lds, n, n_hash, 0, n, true, kind, dout.p, n, nullptr);
+    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, kind, dout.p, n, nullptr);
     if (rc != DA_OK) return rc;
     DA_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * (size_t)n * esz, hipMemcpyDeviceToHost));
     return DA_OK;
   }
   for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
     const int64_t r1 = std::min(row_end, r0 + blk);
-    rc = launch_mh_compare(planes.as<uint32_t>(), lds, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr);
+    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr);
     if (rc != DA_OK) return rc;
     DA_HIP_TRY(hipMemcpy(static_cast<char *>(out) + (size_t)(r0 - row_begin) * (size_t)n * esz, dout.p,
                          (size_t)(r1 - r0) * (size_t)n * esz, hipMemcpyDeviceToHost));

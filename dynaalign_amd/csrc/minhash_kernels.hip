@@ -124,9 +124,10 @@ __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
   if (planes) {
     uint32_t *prow = planes + seq * ld_planes;
     const int lane = threadIdx.x & 63;
-    for (int h0 = 0; h0 < ld_planes; h0 += K1_THREADS) {
+    const int half_ld = (int)(ld_planes >> 1);       // words per copy (multiple of 32)
+    for (int h0 = 0; h0 < half_ld; h0 += K1_THREADS) {
       const int hw = h0 + (threadIdx.x & ~63);       // first h of this wave
-      if (hw >= ld_planes) break;                    // wave-uniform
+      if (hw >= half_ld) break;                      // wave-uniform
       const int h = hw + lane;
       const uint32_t v = (h < n_hash) ? row[h] : 0u;  // own earlier store (same thread wrote row[h])
       uint32_t w = 0;
@@ -136,7 +137,13 @@ __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
         const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
         w = ((lane & 31) == p) ? half : w;
       }
-      if (h < ld_planes) prow[h] = w;
+      // Second copy with each pair of planes swapped (word h^1), stored ld_planes/2 words
+      // further: the compare kernel reads its column operand from it so that the two
+      // plane registers of every v_bitop3 differ in VGPR-index parity (see k_mh_compare).
+      if (h < half_ld) {
+        prow[h] = w;
+        prow[half_ld + (h ^ 1)] = w;
+      }
     }
   }
 }
@@ -292,7 +299,8 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const int seg = (lane & 3) ^ ((sl >> 2) & 3);
     int64_t g = ((s < 128) ? I0 : J0) + k2_row_of_slot(sl);
     if (g > n - 1) g = n - 1;                          // rows past the end: any valid row, never stored
-    src[q] = planes + g * ld_p + seg * 4;
+    // row operand (a) from the plain copy, column operand (b) from the pair-swapped copy
+    src[q] = planes + g * ld_p + ((s < 128) ? 0 : (ld_p >> 1)) + seg * 4;
   }
   auto issue = [&](int stage) {  // stage s holds planes [16 s, 16 s + 16)
     uint4 *base = lds_ab + (stage % K2_NSTAGE) * STAGE_UNITS + wave * 4 * 64;
@@ -331,10 +339,12 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
         const uint4 b = Sb[c * 16 * K2_SEGS];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          uint32_t v = or_xor(d[r][c], a[r].x, b.x);
-          v = or_xor(v, a[r].y, b.y);
-          v = or_xor(v, a[r].z, b.z);
-          d[r][c] = or_xor(v, a[r].w, b.w);
+          // b holds planes (1,0,3,2): plane p sits in registers of opposite index parity in
+          // a and b, so no v_bitop3 has all three sources in one VGPR bank (half rate otherwise)
+          uint32_t v = or_xor(d[r][c], a[r].x, b.y);
+          v = or_xor(v, a[r].y, b.x);
+          v = or_xor(v, a[r].z, b.w);
+          d[r][c] = or_xor(v, a[r].w, b.z);
         }
       }
     }

@@ -41,10 +41,15 @@ def sig_ld(n_hash):
     return int(_capi.load().da_sig_ld(int(n_hash)))
 
 
+def planes_ld(n_hash):
+    return int(_capi.load().da_planes_ld(int(n_hash)))
+
+
 def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=True):
-    """K1.  Returns (sig, planes): int32 tensors (n, sig_ld(n_hash)).  `sig` holds the uint32
-    signatures in columns [0, n_hash); `planes` the same data bit-transposed in groups of 32
-    hash functions -- the operand of mh_compare (None if want_planes is False)."""
+    """K1.  Returns (sig, planes): int32 tensors (n, sig_ld(n_hash)) and (n, planes_ld(n_hash)).
+    `sig` holds the uint32 signatures in columns [0, n_hash); `planes` the same data bit-transposed
+    in groups of 32 hash functions (plus a pair-swapped copy) -- the operand of mh_compare (None if
+    want_planes is False)."""
     lib = _capi.load()
     if not torch.is_tensor(seeds):
         seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32).copy()).to(ds.residues.device)
@@ -53,7 +58,7 @@ def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=
     if out is None:
         out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
     if planes is None and want_planes:
-        planes = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
+        planes = torch.empty((max(ds.n, 1), 2 * ld), dtype=torch.int32, device=ds.residues.device)
     _capi.check(lib.da_dev_minhash_signatures(ds.residues.data_ptr(), ds.offsets.data_ptr(), ds.n, ds.total,
                                               ds.max_len, int(k), int(n_hash), seeds.data_ptr(), out.data_ptr(),
                                               out.stride(0), None if planes is None else planes.data_ptr(),

@@ -122,15 +122,18 @@ int da_nw_pairs(const uint8_t *residues, const int64_t *offsets, int64_t n,
 /* Leading dimension (in uint32 elements) the library uses for signature and
  * bit-plane matrices: n_hash rounded up to a multiple of 32. */
 int64_t da_sig_ld(int n_hash);
+/* Leading dimension of the bit-plane matrix: 2 * da_sig_ld(n_hash) (two copies per row). */
+int64_t da_planes_ld(int n_hash);
 
 /* K1: signature build.
  *   d_sig    : n rows of ld_sig (>= n_hash) uint32 -- the signatures themselves
  *              (src/minHash.cpp:140-157); columns [n_hash, ld_sig) not written.
  *   d_planes : optional (NULL to skip) n rows of ld_planes uint32, ld_planes a
- *              multiple of 32 and >= da_sig_ld(n_hash): the same signatures
+ *              multiple of 64 and >= da_planes_ld(n_hash): the same signatures
  *              bit-transposed in groups of 32 hash functions (word 32g+p = bit p
- *              of sig[32g .. 32g+31]; hash functions >= n_hash read as 0).  This
- *              is the operand of the compare kernel. */
+ *              of sig[32g .. 32g+31]; hash functions >= n_hash read as 0),
+ *              followed at word ld_planes/2 by a second copy with every pair of
+ *              planes swapped (word (32g+p)^1).  Operand of the compare kernel. */
 int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n,
                               int64_t total_residues, int64_t max_len,
                               int k, int n_hash, const uint32_t *d_seeds,

@@ -25,7 +25,9 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        import re
+        m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Kernel_Name"])
+        k = m.group(1) if m else r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(out, "summary.txt"), "w") as fo:
     for k, cs in agg.items():
