@@ -38,13 +38,17 @@ int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_
                               hipStream_t stream);
 int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
-                      void *d_out, int64_t ld, hipStream_t stream);
+                      void *d_out, int64_t ld, hipStream_t stream, int tile_stride = 1,
+                      bool upper_only = false);
+int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, int64_t n, int world, int tile,
+                            int64_t rows_per_rank, bool is_nw, int n_hash, double *d_out, int64_t ld,
+                            hipStream_t stream);
 int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,
                      hipStream_t stream);
 int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,
               int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
               bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
-              int64_t ld_score, hipStream_t stream);
+              int64_t ld_score, hipStream_t stream, int shard_rank = 0, int shard_world = 0);
 int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream);
 int launch_widen(const uint16_t *d_in, double *d_out, int64_t count, bool is_nw, int n_hash,
                  hipStream_t stream);

@@ -263,7 +263,11 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 template <bool SYM, bool F64>
 __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const uint32_t *__restrict__ planes, int64_t ld_p, int64_t n, int n_hash, int64_t row_begin,
-    int64_t row_end, void *__restrict__ out_v, int64_t ld, int64_t ntiles, int64_t per_xcd) {
+    int64_t row_end, int tile_stride, int upper_only, int TR, void *__restrict__ out_v, int64_t ld,
+    int64_t ntiles, int64_t per_xcd) {
+  // Row-block geometry: local tile row q covers global rows row_begin + q*tile_stride*128 + [0,128)
+  // (tile_stride = 1: a contiguous block; = world: the cyclic shard of one rank) and is stored at
+  // local rows q*128 + [0,128) of `out`.  upper_only skips tiles left of the diagonal.
   // ring of 3 stages; a stage = 16 planes of {128 a-rows, 128 b-rows} = 256 x 64 B = 16 KiB
   constexpr int STAGE_UNITS = 2 * K2_TILE * K2_SEGS;
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[K2_NSTAGE * STAGE_UNITS];
@@ -274,11 +278,13 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
   if (L >= ntiles) return;
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
-  const int TR = (int)((row_end - row_begin + K2_TILE - 1) / K2_TILE);
   const TileId tid2 = decode_tile(L, TR, T, SYM);
   if (!tid2.valid) return;
-  const int64_t I0 = row_begin + (int64_t)tid2.ti * K2_TILE;  // global row of tile row 0
+  const int64_t I0 = row_begin + (int64_t)tid2.ti * tile_stride * K2_TILE;  // global row of tile row 0
   const int64_t J0 = (int64_t)tid2.tj * K2_TILE;
+  const int64_t Iloc = (int64_t)tid2.ti * K2_TILE - I0;                     // local row = global row + Iloc
+  if (I0 >= row_end || I0 >= n) return;
+  if (!SYM && upper_only && J0 + K2_TILE <= I0) return;                     // tile entirely left of the diagonal
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     for (int r = 0; r < 8; ++r) {
       const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
       if (gi >= row_end || gi >= n) continue;
-      double *orow = out + (gi - row_begin) * ld;
+      double *orow = out + (gi + Iloc) * ld;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t gj = J0 + 32 * g + 2 * tx;
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     for (int r = 0; r < 8; ++r) {
       const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
       if (gi >= row_end || gi >= n) continue;
-      uint16_t *orow = out + (gi - row_begin) * ld;
+      uint16_t *orow = out + (gi + Iloc) * ld;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t gj = J0 + 32 * g + 2 * tx;
@@ -510,23 +516,68 @@ int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_
   return DA_OK;
 }
 
-int launch_mh_compare(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
-                      void *d_out, int64_t ld, hipStream_t stream) {
+                      void *d_out, int64_t ld, hipStream_t stream, int tile_stride, bool upper_only) {
   if (row_end <= row_begin) return DA_OK;
   const int T = (int)ceil_div(n, K2_TILE);
-  const int TR = (int)ceil_div(row_end - row_begin, K2_TILE);
+  const int TR = (int)ceil_div(ceil_div(row_end - row_begin, K2_TILE), tile_stride);
   const int64_t ntiles = count_tiles(TR, T, symmetric);
   const int64_t per_xcd = ceil_div(ntiles, 8);
   const int64_t nblocks = per_xcd * 8;
   if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
-#define DA_K2(SYM, F64)                                                                          \
-  hipLaunchKernelGGL((k_mh_compare<SYM, F64>), grid, block, 0, stream, d_sig, ld_sig, n, n_hash, \
-                     row_begin, row_end, d_out, ld, ntiles, per_xcd)
+#define DA_K2(SYM, F64)                                                                              \
+  hipLaunchKernelGGL((k_mh_compare<SYM, F64>), grid, block, 0, stream, d_planes, ld_planes, n, n_hash, \
+                     row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd)
   if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true); else DA_K2(true, false); }
   else           { if (kind == DA_OUT_F64) DA_K2(false, true); else DA_K2(false, false); }
 #undef DA_K2
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+// Gathered shards -> final matrix.  G holds, for every rank p, its local rows (cyclic tile rows
+// p, p+world, ... of `tile` rows each, upper-triangular tiles valid); out[i][j] = widen(G[map(min)][max]).
+__global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__restrict__ G, int64_t ld_g, int64_t n,
+                                                          int world, int tile, int64_t rows_per_rank, int is_nw,
+                                                          int n_hash, double *__restrict__ out, int64_t ld) {
+  __shared__ uint16_t t[32][33];
+  const int64_t bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  auto widen = [&](uint32_t v) -> double {
+    if (!is_nw) return (double)v / (double)n_hash;                       // src/minHash.cpp:174
+    const uint32_t ln = v & 255u;
+    if (ln == 0) return __longlong_as_double(0xFFF8000000000000ULL);     // 0/0 as on the reference's host
+    return (double)(v >> 8) / (double)ln;                                // src/pairwiseSeqAlign.cpp:311
+  };
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < n && j < n) {
+      const int64_t tr = i / tile;
+      const int64_t grow = (tr % world) * rows_per_rank + (tr / world) * tile + (i - tr * tile);
+      t[r][tx] = G[grow * ld_g + j];
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < n && j < n && j >= i) out[i * ld + j] = widen(t[r][tx]);     // upper part as computed
+  }
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t j = bj * 32 + r, i = bi * 32 + tx;                     // out[j][i] = upper(i, j)
+    if (i < n && j < n && j > i) out[j * ld + i] = widen(t[tx][r]);
+  }
+}
+
+int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, int64_t n, int world, int tile,
+                            int64_t rows_per_rank, bool is_nw, int n_hash, double *d_out, int64_t ld,
+                            hipStream_t stream) {
+  if (n <= 0) return DA_OK;
+  const unsigned t = (unsigned)ceil_div(n, 32);
+  hipLaunchKernelGGL(k_finalize_sharded, dim3(t, t), dim3(256), 0, stream, d_g, ld_g, n, world, tile, rows_per_rank,
+                     is_nw ? 1 : 0, n_hash, d_out, ld);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
     int f64_out, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
-    int64_t ld_score, int64_t ntiles, int T) {
+    int64_t ld_score, int64_t ntiles, int T, int shard_rank, int shard_world) {
   __shared__ __attribute__((aligned(16))) Cell tab[24 * 24];
   __shared__ uint8_t rowcodes[K3_TILE][NMAX];
   __shared__ int32_t rowlen[K3_TILE];
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   if (L >= ntiles) return;
   int ti, tj;
   bool allow_direct = true, allow_mirror = true;
+  int64_t row_shift = -row_begin;  // local output row = global row + row_shift
   if (symmetric) {
     // row-major over the upper triangle: row t holds T - t tiles
     const double Td = (double)T;
@@ -134,6 +135,16 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     while (t + 1 <= T - 1 && start(t + 1) <= L) ++t;
     ti = (int)t;
     tj = (int)(t + (L - start(t)));
+  } else if (shard_world > 0) {
+    // cyclic shard of one rank: local tile row q is global tile row q*world + rank; only
+    // upper tiles, direct store into local rows q*64 + [0,64) (the mirror is filled after
+    // the all-gather by k_finalize_sharded)
+    const int q = (int)(L / T);
+    ti = q * shard_world + shard_rank;
+    tj = (int)(L % T);
+    if (ti >= T || tj < ti) return;
+    allow_mirror = false;
+    row_shift = (int64_t)q * K3_TILE - (int64_t)ti * K3_TILE;
   } else {
     // row-block request: tile row rt (inside the block) x every tile column tc.
     // tc >= rt is the upper tile itself (direct store); tc < rt is served by
@@ -234,17 +245,17 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
       double v = (double)mt / (double)ln;                    // reference :311
       if (ln == 0) v = __longlong_as_double(0xFFF8000000000000ULL);  // 0/0 on the reference's host (x86 default NaN)
       double *out = reinterpret_cast<double *>(out_v);
-      if (do_direct) out[(i - row_begin) * ld + j] = v;
-      if (do_mirror) out[(j - row_begin) * ld + i] = v;
+      if (do_direct) out[(i + row_shift) * ld + j] = v;
+      if (do_mirror) out[(j + row_shift) * ld + i] = v;
     } else {
       const uint16_t v = (uint16_t)((mt << 8) | (ln & 0xffu));
       uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
-      if (do_direct) out[(i - row_begin) * ld + j] = v;
-      if (do_mirror) out[(j - row_begin) * ld + i] = v;
+      if (do_direct) out[(i + row_shift) * ld + j] = v;
+      if (do_mirror) out[(j + row_shift) * ld + i] = v;
     }
     if (score_out) {
-      if (do_direct) score_out[(i - row_begin) * ld_score + j] = sc;
-      if (do_mirror) score_out[(j - row_begin) * ld_score + i] = sc;
+      if (do_direct) score_out[(i + row_shift) * ld_score + j] = sc;
+      if (do_mirror) score_out[(j + row_shift) * ld_score + i] = sc;
     }
   }
 }
@@ -272,7 +283,7 @@ int matrix_count_host() { return DA_NUM_MATRICES; }
 int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,
               int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
               bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
-              int64_t ld_score, hipStream_t stream) {
+              int64_t ld_score, hipStream_t stream, int shard_rank, int shard_world) {
   if (n <= 0 || row_end <= row_begin) return DA_OK;
   const signed char *tab = matrix_table_host(matrix_id);
   if (!tab) return fail(DA_ERR_BAD_ARG, "matrix id %d out of range", matrix_id);
@@ -288,6 +299,7 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   const int T = (int)ceil_div(n, K3_TILE);
   int64_t ntiles;
   if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
+  else if (shard_world > 0) ntiles = ceil_div(T, shard_world) * (int64_t)T;
   else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
   if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)ntiles), block(K3_THREADS);
@@ -295,7 +307,7 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
 #define DA_K3(NM)                                                                                   \
   hipLaunchKernelGGL(k_nw_short<NM>, grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, f64, d_out, ld, d_score, \
-                     ld_score, ntiles, T)
+                     ld_score, ntiles, T, shard_rank, shard_world)
   if (max_len <= 8) DA_K3(8);
   else if (max_len <= 12) DA_K3(12);
   else if (max_len <= 16) DA_K3(16);

@@ -1,0 +1,128 @@
+"""Row-sharding of the N x N pair space over the GPUs of one node.
+
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  The inputs
+are tiny (2 MB of residues at N = 100k), so every rank holds all sequences and rebuilds all
+signatures itself; only the result is exchanged:
+
+    rank p computes the upper-triangular tiles of tile rows p, p+P, p+2P, ...   (HIP kernel)
+    ONE all-gather of the equally sized compact uint16 blocks                    (RCCL)
+    every rank expands the gathered blocks to the dense float64 matrix          (HIP kernel)
+
+Tile rows are dealt cyclically so that the triangular work is balanced to within one tile
+row.  The compact payload (2 B/pair instead of 8) is what makes the gather affordable: at
+N = 100k, P = 8 each GPU receives 17.5 GB instead of 70 GB.
+
+The orchestration (`Plan`, `all_pairs_sharded`) is independent of where the blocks come from,
+so the world_size-2 gloo tests drive it on CPU with blocks produced by the test oracle; the
+product path (`mh_sharded_step`, `nw_sharded_step`) feeds it from the HIP kernels only.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _capi
+
+MH_TILE, NW_TILE = 128, 64
+
+
+class Plan:
+    """Which rows a rank owns and where they sit in the gathered buffer."""
+
+    def __init__(self, n, rank, world, tile=MH_TILE):
+        self.n, self.rank, self.world, self.tile = int(n), int(rank), int(world), int(tile)
+        self.tiles = -(-self.n // self.tile)                       # tile rows of the pair space
+        self.local_tiles = -(-self.tiles // self.world)            # per rank (padded, equal for all ranks)
+        self.local_rows = self.local_tiles * self.tile
+
+    def owner(self, i):
+        """(rank, local row) of global row i"""
+        t = i // self.tile
+        return t % self.world, (t // self.world) * self.tile + i % self.tile
+
+    def gathered_row(self, i):
+        p, r = self.owner(i)
+        return p * self.local_rows + r
+
+    def my_rows(self):
+        """global rows owned by this rank, in local order (rows >= n are padding and skipped)"""
+        out = []
+        for q in range(self.local_tiles):
+            t = q * self.world + self.rank
+            out.extend(i for i in range(t * self.tile, min((t + 1) * self.tile, self.n)))
+        return out
+
+    def upper_pairs(self):
+        """number of (i, j >= tile start) pairs this rank computes -- for load-balance checks"""
+        tot = 0
+        for q in range(self.local_tiles):
+            t = q * self.world + self.rank
+            if t < self.tiles:
+                rows = min((t + 1) * self.tile, self.n) - t * self.tile
+                tot += rows * (self.n - t * self.tile)
+        return tot
+
+
+def all_pairs_sharded(plan, local_block, gathered, finalize, group=None):
+    """local_block: this rank's compact block (tensor [plan.local_rows, ld]) already computed;
+    gathered: tensor [world * plan.local_rows, ld]; finalize(gathered) -> result.
+    Exactly one collective: all_gather_into_tensor."""
+    if plan.world > 1:
+        # NCCL/RCCL and gloo have no 16-bit integer type; an all-gather only moves bytes
+        dist.all_gather_into_tensor(gathered.view(torch.uint8), local_block.view(torch.uint8), group=group)
+    else:
+        gathered.copy_(local_block)
+    return finalize(gathered)
+
+
+class Workspace:
+    """Per-rank HBM buffers for the sharded path (allocated once, reused every step)."""
+
+    def __init__(self, plan, device="cuda"):
+        self.local = torch.zeros((plan.local_rows, plan.n), dtype=torch.int16, device=device)
+        self.gathered = torch.empty((plan.world * plan.local_rows, plan.n), dtype=torch.int16, device=device)
+
+
+MHWorkspace = Workspace
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def finalize_shards(plan, gathered, is_nw, n_hash, out):
+    _capi.check(_capi.load().da_dev_finalize_shards(gathered.data_ptr(), gathered.stride(0), plan.n, plan.world,
+                                                    1 if is_nw else 0, int(n_hash), out.data_ptr(), out.stride(0),
+                                                    _stream()))
+    return out
+
+
+def mh_local_block(plan, work, planes, n_hash):
+    assert plan.tile == MH_TILE
+    _capi.check(_capi.load().da_dev_mh_compare_shard(planes.data_ptr(), planes.stride(0), plan.n, int(n_hash),
+                                                     plan.rank, plan.world, work.local.data_ptr(),
+                                                     work.local.stride(0), _stream()))
+    return work.local
+
+
+def mh_sharded_step(plan, work, planes, n_hash, out, group=None):
+    """compare (this rank's tiles) -> one all-gather -> dense float64 n x n in `out` on every rank"""
+    mh_local_block(plan, work, planes, n_hash)
+    return all_pairs_sharded(plan, work.local, work.gathered,
+                             lambda g: finalize_shards(plan, g, False, n_hash, out), group)
+
+
+def nw_local_block(plan, work, ds, matrix_name="BLOSUM62", gap_open=10, gap_ext=4):
+    assert plan.tile == NW_TILE
+    lib = _capi.load()
+    mid = lib.da_matrix_id(matrix_name.encode("latin-1"))
+    if mid < 0:
+        _capi.check(_capi.DA_ERR_BAD_MATRIX)
+    _capi.check(lib.da_dev_nw_shard(ds.codes.data_ptr(), ds.offsets.data_ptr(), plan.n, ds.max_len, mid, int(gap_open),
+                                    int(gap_ext), plan.rank, plan.world, work.local.data_ptr(), work.local.stride(0),
+                                    _stream()))
+    return work.local
+
+
+def nw_sharded_step(plan, work, ds, out, matrix_name="BLOSUM62", gap_open=10, gap_ext=4, group=None):
+    nw_local_block(plan, work, ds, matrix_name, gap_open, gap_ext)
+    return all_pairs_sharded(plan, work.local, work.gathered,
+                             lambda g: finalize_shards(plan, g, True, 0, out), group)

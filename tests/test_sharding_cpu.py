@@ -1,0 +1,111 @@
+"""CPU tests of the N>1 path: the row-sharding plan and the single all-gather, run with
+world_size 2 (and 3) over gloo.  There is no CPU compute path in the product, so the ranks'
+blocks are produced here by the test oracle; what is under test is the partition, the exchange
+and the reassembly rule the HIP finalize kernel implements (its GPU twin is in test_gpu_sharding)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from dynaalign_amd import sharding, synth
+
+
+def finalize_reference(plan, gathered, widen):
+    """numpy statement of k_finalize_sharded: out[i][j] = widen(G[row(min(i,j))][max(i,j)])"""
+    n = plan.n
+    rows = np.array([plan.gathered_row(i) for i in range(n)])
+    up = gathered[rows][:, :n]
+    iu = np.triu_indices(n)
+    out = np.empty((n, n), np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out[iu] = widen(up[iu])
+    out.T[iu] = out[iu]
+    return out
+
+
+@pytest.mark.parametrize("n,world,tile", [(1, 1, 128), (100, 2, 128), (128, 2, 128), (129, 2, 128), (1000, 8, 128),
+                                          (1000, 3, 64), (64, 8, 64), (100000, 8, 128)])
+def test_plan_partitions_rows_exactly_once(n, world, tile):
+    plans = [sharding.Plan(n, r, world, tile) for r in range(world)]
+    if n <= 2000:
+        owned = sorted(i for p in plans for i in p.my_rows())
+        assert owned == list(range(n))
+        seen = {plans[0].gathered_row(i) for i in range(n)}
+        assert len(seen) == n and max(seen) < world * plans[0].local_rows
+        for p in plans:
+            for i in p.my_rows():
+                assert p.owner(i)[0] == p.rank
+    assert len({p.local_rows for p in plans}) == 1          # equal blocks: legal all-gather
+    work = [p.upper_pairs() for p in plans]
+    if n >= 50 * world * tile:                               # cyclic dealing balances the triangle
+        assert max(work) / (sum(work) / world) < 1.05
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_main(rank, world, port, n, kind, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res, off = synth.h3n2_like(n, 20)
+        seqs = synth.to_strings(res, off)
+        tile = sharding.MH_TILE if kind == "mh" else sharding.NW_TILE
+        plan = sharding.Plan(n, rank, world, tile)
+        rows = plan.my_rows()
+        local = np.full((plan.local_rows, n), 0x7FFF, np.int16)     # poison: must never be read
+        if kind == "mh":
+            sig = O.signatures(seqs, 4, 64, O.seeds(12345, 64))
+            for i in rows:
+                t0 = (i // tile) * tile
+                cnt = (sig[i][None, :] == sig[t0:]).sum(1).astype(np.uint16)
+                local[plan.owner(i)[1], t0:] = cnt.view(np.int16)
+            widen = lambda v: v.view(np.uint16).astype(np.float64) / 64
+        else:
+            for i in rows:
+                rc, mt, ln, _, _ = O.nw_rows(seqs, i, i + 1)
+                v = ((mt[0] << 8) | ln[0]).astype(np.uint16)
+                local[plan.owner(i)[1], i:] = v[i:].view(np.int16)   # only j >= i is valid for NW
+
+            def widen(v):
+                u = v.view(np.uint16).astype(np.uint32)
+                return (u >> 8).astype(np.float64) / (u & 255).astype(np.float64)
+        local_t = torch.from_numpy(local)
+        gathered = torch.empty((world * plan.local_rows, n), dtype=torch.int16)
+        out = sharding.all_pairs_sharded(plan, local_t, gathered,
+                                         lambda g: finalize_reference(plan, g.numpy(), widen))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,kind", [(2, 300, "mh"), (3, 333, "mh"), (2, 150, "nw")])
+def test_sharded_all_gather_reassembles_the_oracle_matrix(world, n, kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, n, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+    if kind == "mh":
+        rc, want = O.similarity_mh(seqs, 4, 64, O.seeds(12345, 64))
+    else:
+        rc, want, _ = O.similarity_nw(seqs)
+    assert rc == 0
+    for rank, out in results:                                        # every rank ends with the full matrix
+        assert np.array_equal(out.view(np.uint64), want.view(np.uint64)), rank

@@ -8,7 +8,7 @@
 __device__ __forceinline__ unsigned or_xor(unsigned d, unsigned a, unsigned b) { return __builtin_amdgcn_bitop3_b32(d, a, b, 0xF6); }
 
 // NA = a-reads per seg (8 = real), NB = b-reads per seg (8 = real); BARRIER: __syncthreads every 4 segs
-template <int NA, int NB, bool BARRIER, int MINW, bool SWAP = false>
+template <int NA, int NB, bool BARRIER, int MINW, bool SWAP = false, bool ILP = false>
 __global__ __launch_bounds__(256, MINW) void k(unsigned *out, int iters) {
   __shared__ __attribute__((aligned(16))) uint4 lds[3 * 1024];   // 48 KiB
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -40,12 +40,23 @@ __global__ __launch_bounds__(256, MINW) void k(unsigned *out, int iters) {
       for (int c = 0; c < 8; ++c) {
         if (c < NB) b = Sb[c * 64];
         else if (NB == 0) b = make_uint4(d[0][c], d[1][c] + seg, d[2][c], d[3][c]);
+        if (!ILP) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          unsigned v = or_xor(d[r][c], a[r].x, SWAP ? b.y : b.x);
-          v = or_xor(v, a[r].y, SWAP ? b.x : b.y);
-          v = or_xor(v, a[r].z, SWAP ? b.w : b.z);
-          d[r][c] = or_xor(v, a[r].w, SWAP ? b.z : b.w);
+          for (int r = 0; r < 8; ++r) {
+            unsigned v = or_xor(d[r][c], a[r].x, SWAP ? b.y : b.x);
+            v = or_xor(v, a[r].y, SWAP ? b.x : b.y);
+            v = or_xor(v, a[r].z, SWAP ? b.w : b.z);
+            d[r][c] = or_xor(v, a[r].w, SWAP ? b.z : b.w);
+          }
+        } else {  // 8 independent chains between dependent ops
+#pragma unroll
+          for (int r = 0; r < 8; ++r) d[r][c] = or_xor(d[r][c], a[r].x, b.y);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) d[r][c] = or_xor(d[r][c], a[r].y, b.x);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) d[r][c] = or_xor(d[r][c], a[r].z, b.w);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) d[r][c] = or_xor(d[r][c], a[r].w, b.z);
         }
       }
     }
@@ -80,6 +91,8 @@ int main() {
     run("8a+8b b128 reads/seg, barrier/4seg", k<8, 8, true, 3>, bpc, out);
     run("8a+8b swapped pairing, no barrier", k<8, 8, false, 3, true>, bpc, out);
     run("8a+8b swapped pairing, barrier", k<8, 8, true, 3, true>, bpc, out);
+    run("8a+8b swapped + ILP order, barrier", k<8, 8, true, 3, true, true>, bpc, out);
+    run("no LDS, swapped + ILP order", k<0, 0, false, 3, true, true>, bpc, out);
   }
   return 0;
 }
