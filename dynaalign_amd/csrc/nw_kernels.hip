@@ -25,6 +25,7 @@
 //     (reference :340-346; the function is not symmetric); the
 //     mirrored element is stored from the same lane (:349-350).
 #include <climits>
+#include <cstdlib>
 
 #include "da_common.hpp"
 
@@ -108,13 +109,55 @@ __device__ __forceinline__ void nw_row(int32_t (&MG)[NMAX], int32_t (&X)[NMAX], 
   }
 }
 
-template <int NMAX>
+// ---- "combined key" cell update (fast path) ---------------------------------
+// A cell's state is ONE int32:  score * 2^15 + priority * 2^13 + payload, payload =
+// matches * 128 + length.  Signed comparison orders by score first, then by priority
+// (diagonal 2 > up 1 > left 0 -- exactly the reference's tie-break, :271-279), and the
+// payload of the winner rides along, so the choose-and-propagate step is one v_max3
+// instead of two half-rate compares and two v_cndmask (gfx950 issues add/sub/and/bitop3
+// at twice the rate of cmp/cndmask/max).  Valid while scores stay within 17 bits: the
+// launcher uses it for 0 <= gapOpen, gapExt and gapOpen + 64*gapExt <= 7000 with the
+// "minus infinity" sentinel at -24000 (any value below every reachable score gives the
+// same decisions as the reference's INT_MIN/2; the int32 kernel covers everything else).
+constexpr int CK_S = 13, CK_S2 = 15;
+constexpr int32_t CK_LOW = (1 << CK_S2) - 1;   // priority + payload bits
+constexpr int32_t CK_PRI = 3 << CK_S;
+constexpr int32_t CK_NEG = -24000;
+
+//   VM[c] : combined M[r-1][c] (priority cleared)         XP[c] : Ix[r-1][c]*2^15 | payload of cell (r-1,c)
+template <int NMAX, bool FIRST>
+__device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMAX], const uint32_t (&boff)[NMAX],
+                                          const char *tab_row, int32_t vm_diag0, int32_t vm_left0, int32_t yp_left0,
+                                          int32_t cxa, int32_t cxb, int32_t cya, int32_t cyb, int32_t ixf_first,
+                                          int32_t low_mask) {
+  int32_t vmd = vm_diag0, vml = vm_left0, ypl = yp_left0;
+#pragma unroll
+  for (int c = 0; c < NMAX; ++c) {
+    const int32_t e = *reinterpret_cast<const int32_t *>(tab_row + boff[c]);
+    // up: max(M-goe, Ix-ge), priority 1, payload of the cell above + 1     (reference :255-257, :273-275)
+    const int32_t ixf = FIRST ? ixf_first + c : max(VM[c] - cxa, XP[c] - cxb);
+    // left: max(M-goe, Iy-ge), priority 0, payload of the cell to the left + 1        (:260-262, :276-278)
+    const int32_t iyf = max(vml - cya, ypl - cyb);
+    const int32_t vd = vmd + e;                       // diagonal, priority 2, payload + 1 (+128 on a match)  (:265-271)
+    const int32_t w = max(max(vd, ixf), iyf);         // v_max3_i32
+    const int32_t vmn = w & ~CK_PRI;
+    vmd = VM[c];
+    VM[c] = vmn;
+    // (vmn & LOW) | (ixf & ~LOW) as one full-rate v_bitop3 (S0=0xF0,S1=0xCC,S2=0xAA: (S1&S2)|(S0&~S2) = 0xD8)
+    XP[c] = __builtin_amdgcn_bitop3_b32(ixf, vmn, low_mask, 0xD8);
+    ypl = __builtin_amdgcn_bitop3_b32(iyf, vmn, low_mask, 0xD8);
+    vml = vmn;
+  }
+}
+
+template <int NMAX, bool CK>
 __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
     int f64_out, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
     int64_t ld_score, int64_t ntiles, int T, int shard_rank, int shard_world) {
-  __shared__ __attribute__((aligned(16))) Cell tab[24 * 24];
+  __shared__ __attribute__((aligned(16))) Cell tab[CK ? 1 : 24 * 24];
+  __shared__ int32_t tabk[CK ? 24 * 24 : 1];
   __shared__ uint8_t rowcodes[K3_TILE][NMAX];
   __shared__ int32_t rowlen[K3_TILE];
 
@@ -164,8 +207,12 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   // ---- stage the score table and this tile's 64 row sequences in LDS
   for (int e = threadIdx.x; e < 576; e += K3_THREADS) {
     const int a = e / 24, b = e - a * 24;
-    tab[e].s_goe = (int32_t)table.s[e] + goe;
-    tab[e].inc = 1u + ((a == b) ? 0x10000u : 0u);  // equal index <=> equal residue byte (:291-293)
+    if (CK) {
+      tabk[e] = ((int32_t)table.s[e] << CK_S2) + (2 << CK_S) + 1 + ((a == b) ? 128 : 0);
+    } else {
+      tab[e].s_goe = (int32_t)table.s[e] + goe;
+      tab[e].inc = 1u + ((a == b) ? 0x10000u : 0u);  // equal index <=> equal residue byte (:291-293)
+    }
   }
   for (int r = threadIdx.x >> 2; r < K3_TILE; r += K3_THREADS / 4) {
     const int64_t i = I0 + r;
@@ -185,12 +232,13 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const int64_t b = jvalid ? offsets[j] : 0;
     nj = jvalid ? (int32_t)(offsets[j + 1] - b) : 0;
 #pragma unroll
-    for (int c = 0; c < NMAX; ++c) boff[c] = (c < nj ? (uint32_t)codes[b + c] : 0u) * (uint32_t)sizeof(Cell);
+    for (int c = 0; c < NMAX; ++c)
+      boff[c] = (c < nj ? (uint32_t)codes[b + c] : 0u) * (uint32_t)(CK ? sizeof(int32_t) : sizeof(Cell));
   }
   __syncthreads();
 
   const int32_t ix_first = max(NEG - goe, NEG - ge);
-  const char *tab_bytes = reinterpret_cast<const char *>(tab);
+  const char *tab_bytes = CK ? reinterpret_cast<const char *>(tabk) : reinterpret_cast<const char *>(tab);
 
   for (int rr = 0; rr < K3_ROWS_PER_WAVE; ++rr) {
     const int lr = wave * K3_ROWS_PER_WAVE + rr;
@@ -202,6 +250,47 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     if (!want_direct && !want_mirror_any) continue;
     const int32_t m = rowlen[lr];
 
+    uint32_t mt, ln;
+    int32_t sc;
+    if constexpr (CK) {
+      // row 0 (reference :222-235) in combined form: only its max(M,Ix,Iy) feeds row 1's diagonal
+      int32_t VM[NMAX], XP[NMAX];
+#pragma unroll
+      for (int c = 0; c < NMAX; ++c) {
+        VM[c] = ((-go - c * ge) << CK_S2) | (c + 1);   // Iy[0][c+1], payload (0 matches, length c+1)
+        XP[c] = 0;                                      // Ix[0][.] = -inf is handled by FIRST
+      }
+      // wave-uniform constants are parked in VGPRs: an SGPR source halves v_bitop3's issue rate
+      auto in_vgpr = [](int32_t x) { int32_t v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; };
+      const int32_t cxa = in_vgpr((goe << CK_S2) - (1 << CK_S) - 1), cxb = in_vgpr((ge << CK_S2) - (1 << CK_S) - 1);
+      const int32_t cya = in_vgpr((goe << CK_S2) - 1), cyb = in_vgpr((ge << CK_S2) - 1);
+      const int32_t low_mask = in_vgpr(CK_LOW);
+      // Ix[1][c] = max(NEG-goe, NEG-ge), priority 1, payload (0, c+1)+... = length (c+1)+1 added per column
+      const int32_t ixf_first = ((CK_NEG - min(goe, ge)) << CK_S2) + (1 << CK_S) + 2;
+      for (int32_t r = 1; r <= m; ++r) {
+        uint32_t row_off = (uint32_t)rowcodes[lr][r - 1] * (24u * (uint32_t)sizeof(int32_t));
+        asm volatile("" : "+v"(row_off));  // keep it one VGPR: per cell a full-rate v_add, not a v_mad
+        const char *tab_row = tab_bytes + row_off;
+        // column 0 of rows r-1 and r (reference :224-229): max(M,Ix,Iy)[r-1][0] and M = Iy = -inf at (r,0)
+        const int32_t vm_diag0 = (r == 1) ? 0 : (((-go - (r - 2) * ge) << CK_S2) | (r - 1));
+        const int32_t left0 = (CK_NEG << CK_S2) | r;
+        if (r == 1)
+          nw_row_ck<NMAX, true>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask);
+        else
+          nw_row_ck<NMAX, false>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask);
+      }
+      // ---- cell (m, nj)
+      mt = 0; ln = (uint32_t)m;                     // nj == 0: column-0 boundary
+      sc = (m == 0) ? 0 : NEG;
+      if (m == 0) {
+        ln = (uint32_t)nj;
+        sc = (nj == 0) ? 0 : NEG;
+      } else {
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c)
+          if (nj == c + 1) { mt = ((uint32_t)VM[c] >> 7) & 63u; ln = (uint32_t)VM[c] & 127u; sc = VM[c] >> CK_S2; }
+      }
+    } else {
     // row 0 of the DP (reference :222-235)
     int32_t MG[NMAX], X[NMAX];
     uint32_t P[NMAX];
@@ -227,7 +316,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
 
     // ---- cell (m, nj)
     uint32_t p = (uint32_t)m;  // nj == 0: length m, 0 matches (column-0 boundary)
-    int32_t sc = (m == 0) ? 0 : NEG;
+    sc = (m == 0) ? 0 : NEG;
     if (m == 0) {              // no rows were run: the arrays still hold DP row 0
       p = (uint32_t)nj;
       sc = (nj == 0) ? 0 : NEG;
@@ -236,9 +325,11 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
       for (int c = 0; c < NMAX; ++c)
         if (nj == c + 1) { p = P[c]; sc = MG[c] + goe; }
     }
+    mt = p >> 16;
+    ln = p & 0xffffu;
+    }
 
     if (!jvalid || j < i) continue;
-    const uint32_t mt = p >> 16, ln = p & 0xffffu;
     const bool do_direct = want_direct;
     const bool do_mirror = allow_mirror && (j != i) && j >= row_begin && j < row_end;
     if (f64_out) {
@@ -304,8 +395,14 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)ntiles), block(K3_THREADS);
   const int f64 = kind == DA_OUT_F64;
+  // fast path: scores fit the 17-bit field of the combined key (see nw_row_ck)
+  const bool ck = gap_open >= 0 && gap_ext >= 0 && (int64_t)gap_open + 64 * (int64_t)gap_ext <= 7000 &&
+                  !getenv("DYNAALIGN_NW_INT32");
 #define DA_K3(NM)                                                                                   \
-  hipLaunchKernelGGL(k_nw_short<NM>, grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
+  if (ck) hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
+                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, f64, d_out, ld, d_score, \
+                     ld_score, ntiles, T, shard_rank, shard_world);                                  \
+  else hipLaunchKernelGGL((k_nw_short<NM, false>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, f64, d_out, ld, d_score, \
                      ld_score, ntiles, T, shard_rank, shard_world)
   if (max_len <= 8) DA_K3(8);

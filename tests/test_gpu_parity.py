@@ -208,10 +208,21 @@ def test_nw_large_gap_penalties(da):
     """penalties far outside the usual range still agree (int32 arithmetic, NEG sentinel)"""
     from dynaalign_amd import synth
     seqs = synth.to_strings(*synth.uniform_peptides(80, 16, seed=3))
-    for go, ge in ((1000, 1000), (0, 50), (100000, 1), (7, 0)):
+    for go, ge in ((1000, 1000), (0, 50), (100000, 1), (7, 0), (600, 100), (6999, 0), (7001, 0), (-3, 2), (5, -1)):
         rc, omt, oln, osc, _ = O.nw_rows(seqs, 0, None, "BLOSUM62", go, ge)
         mt, ln, sc = da.nw_pairs(seqs, "BLOSUM62", go, ge)
         assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc), (go, ge)
+
+
+def test_nw_int32_kernel_still_agrees(da, golden, monkeypatch):
+    """the general int32 kernel (used when penalties do not fit the combined-key fast path)"""
+    monkeypatch.setenv("DYNAALIGN_NW_INT32", "1")
+    seqs = [str(s) for s in golden["nw_sequences"]]
+    for name, go, ge in (("BLOSUM62", 10, 4), ("BLOSUM80", 0, 0), ("BLOSUM50", 12, 2)):
+        mt, ln, sc = da.nw_pairs(seqs, name, go, ge)
+        tag = "nw_%s_%d_%d" % (name, go, ge)
+        assert np.array_equal(mt, golden[tag + "_matches"]) and np.array_equal(ln, golden[tag + "_len"])
+        assert np.array_equal(sc, golden[tag + "_score"])
 
 
 def test_nw_long_sequences_fail_loudly(da):
