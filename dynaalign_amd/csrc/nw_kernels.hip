@@ -109,6 +109,11 @@ __device__ __forceinline__ void nw_row(int32_t (&MG)[NMAX], int32_t (&X)[NMAX], 
   }
 }
 
+// matches / length exactly as the reference divides them (:311); 0/0 gives the x86 default NaN
+__device__ __forceinline__ double nw_ratio(uint32_t mt, uint32_t ln) {
+  return ln == 0 ? __longlong_as_double(0xFFF8000000000000ULL) : (double)mt / (double)ln;
+}
+
 // ---- "combined key" cell update (fast path) ---------------------------------
 // A cell's state is ONE int32:  score * 2^15 + priority * 2^13 + payload, payload =
 // matches * 128 + length.  Signed comparison orders by score first, then by priority
@@ -129,7 +134,7 @@ template <int NMAX, bool FIRST>
 __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMAX], const uint32_t (&boff)[NMAX],
                                           const char *tab_row, int32_t vm_diag0, int32_t vm_left0, int32_t yp_left0,
                                           int32_t cxa, int32_t cxb, int32_t cya, int32_t cyb, int32_t ixf_first,
-                                          int32_t low_mask) {
+                                          int32_t low_mask, int32_t pri_clear) {
   int32_t vmd = vm_diag0, vml = vm_left0, ypl = yp_left0;
 #pragma unroll
   for (int c = 0; c < NMAX; ++c) {
@@ -140,7 +145,7 @@ __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMA
     const int32_t iyf = max(vml - cya, ypl - cyb);
     const int32_t vd = vmd + e;                       // diagonal, priority 2, payload + 1 (+128 on a match)  (:265-271)
     const int32_t w = max(max(vd, ixf), iyf);         // v_max3_i32
-    const int32_t vmn = w & ~CK_PRI;
+    const int32_t vmn = w & pri_clear;
     vmd = VM[c];
     VM[c] = vmn;
     // (vmn & LOW) | (ixf & ~LOW) as one full-rate v_bitop3 (S0=0xF0,S1=0xCC,S2=0xAA: (S1&S2)|(S0&~S2) = 0xD8)
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   __shared__ int32_t tabk[CK ? 24 * 24 : 1];
   __shared__ uint8_t rowcodes[K3_TILE][NMAX];
   __shared__ int32_t rowlen[K3_TILE];
+  __shared__ uint32_t mirror_res[K3_THREADS / 64][K3_ROWS_PER_WAVE][64];
 
   // ---- tile decode (upper-triangular 64x64 tiles of the pair space)
   const int64_t L = blockIdx.x;
@@ -240,6 +246,14 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   const int32_t ix_first = max(NEG - goe, NEG - ge);
   const char *tab_bytes = CK ? reinterpret_cast<const char *>(tabk) : reinterpret_cast<const char *>(tab);
 
+  // The mirrored element of row i lands in row j of the output: one lane, one row.  Storing it
+  // per DP row would scatter 8-byte writes over 64 cache lines per instruction (3x write
+  // amplification measured); instead a lane parks its 16 results in LDS (own slot, no sync
+  // needed) and stores them as one contiguous, line-aligned run out[j][i0 .. i0+15] at the end.
+  uint32_t *my_res = &mirror_res[wave][0][lane];
+#pragma unroll
+  for (int rr = 0; rr < K3_ROWS_PER_WAVE; ++rr) my_res[rr * 64] = 0xffffffffu;  // = nothing to mirror
+
   for (int rr = 0; rr < K3_ROWS_PER_WAVE; ++rr) {
     const int lr = wave * K3_ROWS_PER_WAVE + rr;
     const int64_t i = I0 + lr;
@@ -264,20 +278,21 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
       auto in_vgpr = [](int32_t x) { int32_t v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; };
       const int32_t cxa = in_vgpr((goe << CK_S2) - (1 << CK_S) - 1), cxb = in_vgpr((ge << CK_S2) - (1 << CK_S) - 1);
       const int32_t cya = in_vgpr((goe << CK_S2) - 1), cyb = in_vgpr((ge << CK_S2) - 1);
-      const int32_t low_mask = in_vgpr(CK_LOW);
+      const int32_t low_mask = in_vgpr(CK_LOW), pri_clear = in_vgpr(~CK_PRI);
       // Ix[1][c] = max(NEG-goe, NEG-ge), priority 1, payload (0, c+1)+... = length (c+1)+1 added per column
       const int32_t ixf_first = ((CK_NEG - min(goe, ge)) << CK_S2) + (1 << CK_S) + 2;
       for (int32_t r = 1; r <= m; ++r) {
-        uint32_t row_off = (uint32_t)rowcodes[lr][r - 1] * (24u * (uint32_t)sizeof(int32_t));
-        asm volatile("" : "+v"(row_off));  // keep it one VGPR: per cell a full-rate v_add, not a v_mad
+        // (making this offset opaque to the compiler turns the per-cell v_mad into a v_add but lets it
+        // hoist all 20 lookups: 141 VGPRs / 3 waves per SIMD and 15 % slower -- measured, not kept)
+        const uint32_t row_off = (uint32_t)rowcodes[lr][r - 1] * (24u * (uint32_t)sizeof(int32_t));
         const char *tab_row = tab_bytes + row_off;
         // column 0 of rows r-1 and r (reference :224-229): max(M,Ix,Iy)[r-1][0] and M = Iy = -inf at (r,0)
         const int32_t vm_diag0 = (r == 1) ? 0 : (((-go - (r - 2) * ge) << CK_S2) | (r - 1));
         const int32_t left0 = (CK_NEG << CK_S2) | r;
         if (r == 1)
-          nw_row_ck<NMAX, true>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask);
+          nw_row_ck<NMAX, true>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask, pri_clear);
         else
-          nw_row_ck<NMAX, false>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask);
+          nw_row_ck<NMAX, false>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask, pri_clear);
       }
       // ---- cell (m, nj)
       mt = 0; ln = (uint32_t)m;                     // nj == 0: column-0 boundary
@@ -332,21 +347,45 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     if (!jvalid || j < i) continue;
     const bool do_direct = want_direct;
     const bool do_mirror = allow_mirror && (j != i) && j >= row_begin && j < row_end;
-    if (f64_out) {
-      double v = (double)mt / (double)ln;                    // reference :311
-      if (ln == 0) v = __longlong_as_double(0xFFF8000000000000ULL);  // 0/0 on the reference's host (x86 default NaN)
-      double *out = reinterpret_cast<double *>(out_v);
-      if (do_direct) out[(i + row_shift) * ld + j] = v;
-      if (do_mirror) out[(j + row_shift) * ld + i] = v;
-    } else {
-      const uint16_t v = (uint16_t)((mt << 8) | (ln & 0xffu));
-      uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
-      if (do_direct) out[(i + row_shift) * ld + j] = v;
-      if (do_mirror) out[(j + row_shift) * ld + i] = v;
+    if (do_mirror) my_res[rr * 64] = (mt << 16) | ln;
+    if (do_direct) {
+      if (f64_out) {
+        reinterpret_cast<double *>(out_v)[(i + row_shift) * ld + j] = nw_ratio(mt, ln);
+      } else {
+        reinterpret_cast<uint16_t *>(out_v)[(i + row_shift) * ld + j] = (uint16_t)((mt << 8) | (ln & 0xffu));
+      }
     }
     if (score_out) {
       if (do_direct) score_out[(i + row_shift) * ld_score + j] = sc;
       if (do_mirror) score_out[(j + row_shift) * ld_score + i] = sc;
+    }
+  }
+
+  // ---- mirrored run of this lane: out[j][i0 + q], q = 0..15
+  if (jvalid && allow_mirror) {
+    const int64_t i0 = I0 + wave * K3_ROWS_PER_WAVE;
+    const int64_t base = (j + row_shift) * ld + i0;
+    if (f64_out) {
+      double *o = reinterpret_cast<double *>(out_v) + base;
+      const bool aligned = (reinterpret_cast<uintptr_t>(o) & 15) == 0;
+#pragma unroll 1
+      for (int q = 0; q < K3_ROWS_PER_WAVE; q += 2) {
+        const uint32_t r0 = my_res[q * 64], r1 = my_res[(q + 1) * 64];
+        const bool v0 = r0 != 0xffffffffu, v1 = r1 != 0xffffffffu;
+        if (v0 && v1 && aligned) {
+          *reinterpret_cast<double2 *>(o + q) = make_double2(nw_ratio(r0 >> 16, r0 & 0xffffu), nw_ratio(r1 >> 16, r1 & 0xffffu));
+        } else {
+          if (v0) o[q] = nw_ratio(r0 >> 16, r0 & 0xffffu);
+          if (v1) o[q + 1] = nw_ratio(r1 >> 16, r1 & 0xffffu);
+        }
+      }
+    } else {
+      uint16_t *o = reinterpret_cast<uint16_t *>(out_v) + base;
+#pragma unroll 1
+      for (int q = 0; q < K3_ROWS_PER_WAVE; ++q) {
+        const uint32_t r0 = my_res[q * 64];
+        if (r0 != 0xffffffffu) o[q] = (uint16_t)(((r0 >> 16) << 8) | (r0 & 0xffu));
+      }
     }
   }
 }

@@ -10,6 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu $*"
+export BENCH_ARGS="$ARGS"
 run() { # name, counters...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
@@ -29,6 +30,14 @@ for f in glob.glob(os.path.join(out, "*", "*", "*counter_collection.csv")):
         m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Kernel_Name"])
         k = m.group(1) if m else r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+n = 100000
+argv = os.environ.get("BENCH_ARGS", "").split()
+if "--n" in argv: n = int(argv[argv.index("--n") + 1])
+json.dump({"n": n, "bench_args": os.environ.get("BENCH_ARGS", ""), "note": "rocprofv3 --pmc, one pass per counter group; "
+           "values are per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-counts wide reads 2x on gfx950)",
+           "kernels": {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}},
+          open(os.path.join(out, "summary.json"), "w"), indent=1)
 with open(os.path.join(out, "summary.txt"), "w") as fo:
     for k, cs in agg.items():
         fo.write(k + "\n")
