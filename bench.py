@@ -67,9 +67,25 @@ print(json.dumps({"pairs": pairs, "dt": dt, "threads": O.num_threads()}))
 """
 
 
+def cpu_threads():
+    """Host threads for the CPU baseline: the box's CPU share (gpurun grants 16 per GPU), never more
+    than the cores we may run on -- 128 OpenMP threads on a 16-CPU quota thrash instead of compute."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, int(os.environ.get("DYNAALIGN_CPU_THREADS", "16"))))
+
+
 def cpu_leg(kind, n, rows, gen):
-    out = subprocess.check_output([sys.executable, "-c", _CPU_LEG, kind, str(n), str(rows), gen, ROOT])
-    return json.loads(out.decode().strip().splitlines()[-1])
+    t = time.perf_counter()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cpu_threads()), OMP_WAIT_POLICY="passive")
+    out = subprocess.check_output([sys.executable, "-c", _CPU_LEG, kind, str(n), str(rows), gen, ROOT], timeout=240,
+                                  env=env)
+    r = json.loads(out.decode().strip().splitlines()[-1])
+    print("[bench] cpu leg %s n=%d rows=%d: %.1f s in the oracle, %.1f s wall" % (kind, n, rows, r["dt"],
+                                                                               time.perf_counter() - t), file=sys.stderr)
+    return r
 
 
 def cpu_baseline(gen, target_s):
@@ -77,7 +93,7 @@ def cpu_baseline(gen, target_s):
     sites for MH, serial NW) on a bounded sample of the same workload, in a child process."""
     probe = cpu_leg("mh", 1500, 0, gen)
     rate = probe["pairs"] / probe["dt"]
-    ns = int(min(24000, max(2000, (2 * rate * target_s) ** 0.5)))
+    ns = int(min(16000, max(2000, (2 * rate * target_s) ** 0.5)))
     mh = cpu_leg("mh", ns, 0, gen)
     rows = max(20, int(target_s / (4000 * 2.5e-6)))      # ~2.5 us per 20-mer pair on one core
     nw = cpu_leg("nw", 4000, min(rows, 4000), gen)
