@@ -93,7 +93,7 @@ def cpu_baseline(gen, target_s):
     sites for MH, serial NW) on a bounded sample of the same workload, in a child process."""
     probe = cpu_leg("mh", 1500, 0, gen)
     rate = probe["pairs"] / probe["dt"]
-    ns = int(min(16000, max(2000, (2 * rate * target_s) ** 0.5)))
+    ns = int(min(32000, max(2000, (2 * rate * target_s) ** 0.5)))
     mh = cpu_leg("mh", ns, 0, gen)
     rows = max(20, int(target_s / (4000 * 2.5e-6)))      # ~2.5 us per 20-mer pair on one core
     nw = cpu_leg("nw", 4000, min(rows, 4000), gen)

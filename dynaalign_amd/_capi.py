@@ -16,7 +16,7 @@ DA_OK = 0
 DA_ERR_EMPTY_INPUT, DA_ERR_BAD_K, DA_ERR_BAD_NHASH, DA_ERR_BAD_MATRIX = 1, 2, 3, 4
 DA_ERR_BAD_RESIDUE_SEQ1, DA_ERR_BAD_RESIDUE_SEQ2, DA_ERR_NOMEM, DA_ERR_NO_DEVICE = 5, 6, 7, 8
 DA_ERR_HIP, DA_ERR_UNSUPPORTED, DA_ERR_BAD_ARG = 9, 10, 11
-DA_OUT_F64, DA_OUT_COMPACT = 0, 1
+DA_OUT_F64, DA_OUT_COMPACT, DA_OUT_PACK32 = 0, 1, 2
 
 _vp, _i64, _i32, _u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32
 

@@ -241,7 +241,7 @@ int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64
   if (symmetric && (row_begin != 0 || row_end != n))
     return fail(DA_ERR_BAD_ARG, "symmetric mode needs the full row range");
   if (ld < n || (d_score && ld_score < n)) return fail(DA_ERR_BAD_ARG, "leading dimension < n");
-  if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "bad output kind");
+  if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT && kind != DA_OUT_PACK32) return fail(DA_ERR_BAD_ARG, "bad output kind");
   return launch_nw(d_codes, d_offsets, n, max_len, matrix_id, gap_open, gap_ext, row_begin, row_end,
                    symmetric != 0, kind, d_out, ld, d_score, ld_score, static_cast<hipStream_t>(stream));
 }
@@ -440,24 +440,24 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
     }
     return DA_OK;
   }
-  // integer outputs: compact (matches<<8|len) + score, widened on the host
-  const int64_t blk = rows_per_block(n, sizeof(uint16_t) + sizeof(int32_t));
+  // integer outputs: 32-bit packed (matches<<16|len) + score, unpacked on the host
+  const int64_t blk = rows_per_block(n, sizeof(uint32_t) + sizeof(int32_t));
   DevBuf dpk, dsc;
   const int64_t brow = std::min(blk, rows_total);
-  if ((rc = dpk.alloc((size_t)brow * (size_t)n * sizeof(uint16_t))) != DA_OK) return rc;
+  if ((rc = dpk.alloc((size_t)brow * (size_t)n * sizeof(uint32_t))) != DA_OK) return rc;
   if (score_out && (rc = dsc.alloc((size_t)brow * (size_t)n * sizeof(int32_t))) != DA_OK) return rc;
-  std::vector<uint16_t> hpk((size_t)brow * (size_t)n);
+  std::vector<uint32_t> hpk((size_t)brow * (size_t)n);
   for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
     const int64_t r1 = std::min(row_end, r0 + blk);
     const bool whole = (r0 == 0 && r1 == n);
     rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, r0, r1, whole,
-                   DA_OUT_COMPACT, dpk.p, n, score_out ? dsc.as<int32_t>() : nullptr, n, nullptr);
+                   DA_OUT_PACK32, dpk.p, n, score_out ? dsc.as<int32_t>() : nullptr, n, nullptr);
     if (rc != DA_OK) return rc;
     const size_t cnt = (size_t)(r1 - r0) * (size_t)n, base = (size_t)(r0 - row_begin) * (size_t)n;
-    DA_HIP_TRY(hipMemcpy(hpk.data(), dpk.p, cnt * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    DA_HIP_TRY(hipMemcpy(hpk.data(), dpk.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t e = 0; e < cnt; ++e) {
-      if (matches_out) matches_out[base + e] = hpk[e] >> 8;
-      if (len_out) len_out[base + e] = hpk[e] & 255;
+      if (matches_out) matches_out[base + e] = (int32_t)(hpk[e] >> 16);
+      if (len_out) len_out[base + e] = (int32_t)(hpk[e] & 0xffffu);
     }
     if (score_out) DA_HIP_TRY(hipMemcpy(score_out + base, dsc.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
   }

@@ -80,7 +80,7 @@ __device__ __forceinline__ void nw_row(int32_t (&MG)[NMAX], int32_t (&X)[NMAX], 
                                        const uint32_t (&boff)[NMAX], const char *tab_row,
                                        int32_t mg_diag0, uint32_t p_diag0, uint32_t p_left0,
                                        int32_t mg_left0, int32_t y_left0, int32_t ge, int32_t goe,
-                                       int32_t ix_first) {
+                                       int32_t ix_first, int32_t *y_last = nullptr) {
   int32_t mgd = mg_diag0;   // (max(M,Ix,Iy)[r-1][c-1]) - goe
   uint32_t pd = p_diag0;
   int32_t mgl = mg_left0;   // M[r][c-1] - goe
@@ -107,6 +107,7 @@ __device__ __forceinline__ void nw_row(int32_t (&MG)[NMAX], int32_t (&X)[NMAX], 
     X[c] = ix;
     P[c] = p_new;
   }
+  if (y_last) *y_last = yl;
 }
 
 // matches / length exactly as the reference divides them (:311); 0/0 gives the x86 default NaN
@@ -159,8 +160,9 @@ template <int NMAX, bool CK>
 __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
-    int f64_out, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
+    int kind, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
     int64_t ld_score, int64_t ntiles, int T, int shard_rank, int shard_world) {
+  const bool f64_out = kind == DA_OUT_F64;
   __shared__ __attribute__((aligned(16))) Cell tab[CK ? 1 : 24 * 24];
   __shared__ int32_t tabk[CK ? 24 * 24 : 1];
   __shared__ uint8_t rowcodes[K3_TILE][NMAX];
@@ -351,6 +353,8 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     if (do_direct) {
       if (f64_out) {
         reinterpret_cast<double *>(out_v)[(i + row_shift) * ld + j] = nw_ratio(mt, ln);
+      } else if (kind == DA_OUT_PACK32) {
+        reinterpret_cast<uint32_t *>(out_v)[(i + row_shift) * ld + j] = (mt << 16) | ln;
       } else {
         reinterpret_cast<uint16_t *>(out_v)[(i + row_shift) * ld + j] = (uint16_t)((mt << 8) | (ln & 0xffu));
       }
@@ -379,6 +383,13 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
           if (v1) o[q + 1] = nw_ratio(r1 >> 16, r1 & 0xffffu);
         }
       }
+    } else if (kind == DA_OUT_PACK32) {
+      uint32_t *o = reinterpret_cast<uint32_t *>(out_v) + base;
+#pragma unroll 1
+      for (int q = 0; q < K3_ROWS_PER_WAVE; ++q) {
+        const uint32_t r0 = my_res[q * 64];
+        if (r0 != 0xffffffffu) o[q] = r0;
+      }
     } else {
       uint16_t *o = reinterpret_cast<uint16_t *>(out_v) + base;
 #pragma unroll 1
@@ -387,6 +398,171 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
         if (r0 != 0xffffffffu) o[q] = (uint16_t)(((r0 >> 16) << 8) | (r0 & 0xffu));
       }
     }
+  }
+}
+
+
+// ---------------------------------------------------------------- K4 --
+// k_nw_long: sequences longer than the register-resident kernel takes (up to
+// K4_MAXLEN residues).  ONE WAVEFRONT PER PAIR, anti-diagonal ("systolic")
+// order: lane l owns W consecutive columns of the DP matrix and at step t
+// works on row t - l + 1, so the 64 lanes sit on one anti-diagonal band of the
+// matrix.  A lane's rolling state (M-goe, Ix, matches/len for its W columns)
+// stays in registers; the only cross-lane traffic is the last column of lane
+// l-1 handed to lane l once per step (three 32-bit wave shifts).  sequence1
+// sits in LDS (one byte per residue, per wave), the score table in LDS.
+// Same int32 recurrence, boundary and tie-break as k_nw_short<.., false>
+// (reference src/pairwiseSeqAlign.cpp:222-281), same forward-propagated
+// (matches, length) instead of the traceback (:284-308).
+constexpr int K4_THREADS = 256;
+constexpr int K4_MAXLEN = 1024;   // 64 lanes x W <= 16 columns
+constexpr int K4_TILE = 8;        // pairs per tile side; a wave takes 2 rows x 8 columns
+
+template <int W>
+__global__ __launch_bounds__(K4_THREADS) void k_nw_long(
+    const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n, ScoreTable table,
+    int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric, int kind,
+    void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out, int64_t ld_score,
+    int64_t ntiles, int T) {
+  __shared__ __attribute__((aligned(16))) Cell tab[24 * 24];
+  __shared__ uint8_t seq1[K4_THREADS / 64][K4_MAXLEN];
+
+  const int64_t L = blockIdx.x;
+  if (L >= ntiles) return;
+  int ti, tj;
+  bool allow_direct = true, allow_mirror = true;
+  if (symmetric) {  // row-major over the upper triangle of 8x8-pair tiles
+    const double Td = (double)T;
+    int64_t t = (int64_t)(Td + 0.5 - sqrt((Td + 0.5) * (Td + 0.5) - 2.0 * (double)L));
+    if (t < 0) t = 0;
+    if (t > T - 1) t = T - 1;
+    auto start = [&](int64_t r) { return r * T - r * (r - 1) / 2; };
+    while (t > 0 && start(t) > L) --t;
+    while (t + 1 <= T - 1 && start(t + 1) <= L) ++t;
+    ti = (int)t;
+    tj = (int)(t + (L - start(t)));
+  } else {          // row block: see k_nw_short
+    const int rt = (int)(row_begin / K4_TILE) + (int)(L / T);
+    const int tc = (int)(L % T);
+    ti = tc >= rt ? rt : tc;
+    tj = tc >= rt ? tc : rt;
+    allow_direct = tc >= rt;
+    allow_mirror = tc <= rt;
+  }
+  const int64_t I0 = (int64_t)ti * K4_TILE, J0 = (int64_t)tj * K4_TILE;
+  const int32_t goe = go + ge;
+  const int32_t NEG = INT_MIN / 2;
+  const int32_t ix_first = max(NEG - goe, NEG - ge);
+
+  for (int e = threadIdx.x; e < 576; e += K4_THREADS) {
+    const int a = e / 24, b = e - a * 24;
+    tab[e].s_goe = (int32_t)table.s[e] + goe;
+    tab[e].inc = 1u + ((a == b) ? 0x10000u : 0u);
+  }
+  __syncthreads();
+  const char *tab_bytes = reinterpret_cast<const char *>(tab);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t *s1 = seq1[wave];
+
+  for (int ri = 0; ri < 2; ++ri) {
+    const int64_t i = I0 + wave * 2 + ri;
+    if (i >= n) break;
+    const int64_t b1 = offsets[i];
+    const int32_t m = (int32_t)(offsets[i + 1] - b1);
+    for (int q = lane; q < m; q += 64) s1[q] = codes[b1 + q];   // same wave reads it back: program order suffices
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    for (int cj = 0; cj < K4_TILE; ++cj) {
+      const int64_t j = J0 + cj;
+      if (j >= n || j < i) continue;
+      const bool do_direct = allow_direct && i >= row_begin && i < row_end;
+      const bool do_mirror = allow_mirror && j != i && j >= row_begin && j < row_end;
+      if (!do_direct && !do_mirror) continue;
+      const int64_t b2 = offsets[j];
+      const int32_t nn = (int32_t)(offsets[j + 1] - b2);
+
+      uint32_t p_res = 0;       // matches<<16 | len of cell (m, nn)
+      int32_t sc_res = NEG;
+      if (m == 0 || nn == 0) {  // boundary cells (reference :222-235)
+        p_res = (uint32_t)(m == 0 ? nn : m);
+        sc_res = (m == 0 && nn == 0) ? 0 : NEG;
+      } else {
+        const int la = (nn + W - 1) / W;          // lanes that own at least one real column
+        const int c_first = lane * W;             // global column index (0-based) of this lane's first column - 1
+        uint32_t boff[W];
+        int32_t MG[W], X[W];
+        uint32_t P[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const int c = c_first + w;              // column c+1
+          boff[w] = (c < nn ? (uint32_t)codes[b2 + c] : 0u) * (uint32_t)sizeof(Cell);
+          MG[w] = max(NEG, -go - c * ge) - goe;   // max(M,Ix,Iy)[0][c+1] - goe
+          X[w] = NEG;
+          P[w] = (uint32_t)(c + 1);
+        }
+        // what lane l-1 hands over: state of column c_first (its last column) at the row this lane
+        // is about to process; "prev" = the same for the row before (the diagonal neighbour)
+        int32_t mg_prev = (lane == 0) ? -goe : (max(NEG, -go - (c_first - 1) * ge) - goe);  // max(M,Ix,Iy)[0][c_first] - goe
+        uint32_t p_prev = (uint32_t)c_first;                                                // (0 matches, length c_first)
+        int32_t mg_send = 0, y_send = 0;
+        uint32_t p_send = 0;
+        const int own_lane = (nn - 1) / W, own_w = (nn - 1) - own_lane * W;
+        const int steps = m + la - 1;
+        for (int t = 0; t < steps; ++t) {
+          // shift the last-column state one lane up (lane 0 takes the column-0 boundary, :224-229)
+          int32_t mg_in = __shfl_up(mg_send, 1);
+          int32_t y_in = __shfl_up(y_send, 1);
+          uint32_t p_in = (uint32_t)__shfl_up((int)p_send, 1);
+          const int r = t - lane + 1;             // DP row of this lane in this step
+          if (lane == 0) { mg_in = NEG - goe; y_in = NEG; p_in = (uint32_t)r; }
+          if (lane < la && r >= 1 && r <= m) {
+            const uint32_t a = s1[r - 1];
+            const char *tab_row = tab_bytes + a * (24u * (uint32_t)sizeof(Cell));
+            int32_t y_out;
+            if (r == 1)
+              nw_row<W, true>(MG, X, P, boff, tab_row, mg_prev, p_prev, p_in, mg_in, y_in, ge, goe, ix_first, &y_out);
+            else
+              nw_row<W, false>(MG, X, P, boff, tab_row, mg_prev, p_prev, p_in, mg_in, y_in, ge, goe, ix_first, &y_out);
+            // column c_first at row r becomes the diagonal neighbour of row r+1
+            mg_prev = (lane == 0) ? (max(NEG, -go - (r - 1) * ge) - goe) : mg_in;   // lane 0: max(M,Ix,Iy)[r][0] = Ix[r][0]
+            p_prev = p_in;
+            mg_send = MG[W - 1];
+            y_send = y_out;
+            p_send = P[W - 1];
+            if (r == m && lane == own_lane) {
+#pragma unroll
+              for (int w = 0; w < W; ++w)
+                if (w == own_w) { p_res = P[w]; sc_res = MG[w] + goe; }
+            }
+          }
+        }
+        p_res = (uint32_t)__shfl((int)p_res, own_lane);
+        sc_res = __shfl(sc_res, own_lane);
+      }
+
+      if (lane == 0) {
+        const uint32_t mt = p_res >> 16, ln = p_res & 0xffffu;
+        const int64_t od = (i - row_begin) * ld + j, om = (j - row_begin) * ld + i;
+        if (kind == DA_OUT_F64) {
+          const double v = nw_ratio(mt, ln);
+          if (do_direct) reinterpret_cast<double *>(out_v)[od] = v;
+          if (do_mirror) reinterpret_cast<double *>(out_v)[om] = v;
+        } else if (kind == DA_OUT_PACK32) {
+          if (do_direct) reinterpret_cast<uint32_t *>(out_v)[od] = p_res;
+          if (do_mirror) reinterpret_cast<uint32_t *>(out_v)[om] = p_res;
+        } else {
+          const uint16_t v = (uint16_t)((mt << 8) | (ln & 0xffu));
+          if (do_direct) reinterpret_cast<uint16_t *>(out_v)[od] = v;
+          if (do_mirror) reinterpret_cast<uint16_t *>(out_v)[om] = v;
+        }
+        if (score_out) {
+          if (do_direct) score_out[(i - row_begin) * ld_score + j] = sc_res;
+          if (do_mirror) score_out[(j - row_begin) * ld_score + i] = sc_res;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // next row overwrites s1
   }
 }
 
@@ -417,13 +593,39 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   if (n <= 0 || row_end <= row_begin) return DA_OK;
   const signed char *tab = matrix_table_host(matrix_id);
   if (!tab) return fail(DA_ERR_BAD_ARG, "matrix id %d out of range", matrix_id);
-  if (max_len > 32)
+  if (max_len > K4_MAXLEN)
     return fail(DA_ERR_UNSUPPORTED,
-                "similarityNW on gfx950 currently handles sequences up to 32 residues "
-                "(longest here: %lld); the long-sequence kernel is not built yet",
+                "similarityNW on gfx950 handles sequences up to %d residues (longest here: %lld)", K4_MAXLEN,
                 (long long)max_len);
   if (kind == DA_OUT_COMPACT && max_len > 127)
-    return fail(DA_ERR_UNSUPPORTED, "compact NW output needs alignment length <= 255");
+    return fail(DA_ERR_UNSUPPORTED, "uint16 NW output needs alignment length <= 255 (use the float64 or 32-bit packed kind)");
+  if (max_len > 32) {  // wavefront-per-pair anti-diagonal kernel
+    if (shard_world > 0) return fail(DA_ERR_UNSUPPORTED, "row-sharded NW is built for sequences up to 32 residues");
+    ScoreTable st4;
+    for (int e = 0; e < 576; ++e) st4.s[e] = tab[e];
+    const int T8 = (int)ceil_div(n, K4_TILE);
+    int64_t nt;
+    if (symmetric) nt = (int64_t)T8 * (T8 + 1) / 2;
+    else nt = ((row_end - 1) / K4_TILE - row_begin / K4_TILE + 1) * (int64_t)T8;
+    if (nt > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
+    dim3 grid4((unsigned)nt), block4(K4_THREADS);
+#define DA_K4(WW)                                                                                              \
+  hipLaunchKernelGGL(k_nw_long<WW>, grid4, block4, 0, stream, d_codes, d_off, n, st4, (int32_t)gap_open,      \
+                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, ld_score, nt, T8)
+    const int wneed = (int)ceil_div(max_len, 64);   // columns per lane so that 64 lanes cover the longest sequence
+    if (wneed <= 1) DA_K4(1);
+    else if (wneed <= 2) DA_K4(2);
+    else if (wneed <= 3) DA_K4(3);
+    else if (wneed <= 4) DA_K4(4);
+    else if (wneed <= 6) DA_K4(6);
+    else if (wneed <= 8) DA_K4(8);
+    else if (wneed <= 9) DA_K4(9);
+    else if (wneed <= 12) DA_K4(12);
+    else DA_K4(16);
+#undef DA_K4
+    DA_HIP_TRY(hipGetLastError());
+    return DA_OK;
+  }
   ScoreTable st;
   for (int e = 0; e < 576; ++e) st.s[e] = tab[e];
   const int T = (int)ceil_div(n, K3_TILE);
@@ -433,16 +635,15 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
   if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)ntiles), block(K3_THREADS);
-  const int f64 = kind == DA_OUT_F64;
   // fast path: scores fit the 17-bit field of the combined key (see nw_row_ck)
   const bool ck = gap_open >= 0 && gap_ext >= 0 && (int64_t)gap_open + 64 * (int64_t)gap_ext <= 7000 &&
                   !getenv("DYNAALIGN_NW_INT32");
 #define DA_K3(NM)                                                                                   \
   if (ck) hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
-                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, f64, d_out, ld, d_score, \
+                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
                      ld_score, ntiles, T, shard_rank, shard_world);                                  \
   else hipLaunchKernelGGL((k_nw_short<NM, false>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
-                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, f64, d_out, ld, d_score, \
+                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
                      ld_score, ntiles, T, shard_rank, shard_world)
   if (max_len <= 8) DA_K3(8);
   else if (max_len <= 12) DA_K3(12);

@@ -64,7 +64,8 @@ enum da_status {
 /* element type of a device-side similarity block */
 enum da_out_kind {
   DA_OUT_F64 = 0,    /* double: MH matches/n_hash (src/minHash.cpp:174), NW matches/len (src/pairwiseSeqAlign.cpp:311) */
-  DA_OUT_COMPACT = 1 /* uint16: MH match count; NW (matches << 8 | len) -- valid for len <= 255 */
+  DA_OUT_COMPACT = 1, /* uint16: MH match count; NW (matches << 8 | len) -- valid for len <= 255 */
+  DA_OUT_PACK32 = 2   /* uint32, NW only: (matches << 16 | len) -- any supported length */
 };
 
 const char *da_last_error(void);

@@ -225,10 +225,53 @@ def test_nw_int32_kernel_still_agrees(da, golden, monkeypatch):
         assert np.array_equal(sc, golden[tag + "_score"])
 
 
-def test_nw_long_sequences_fail_loudly(da):
+def _rand_seqs(rng, lengths, alphabet="ARNDCQEGHILKMFPSTWYVBZX*"):
+    return ["".join(alphabet[i] for i in rng.randint(0, len(alphabet), L)) for L in lengths]
+
+
+@pytest.mark.parametrize("lengths", [
+    (33, 40, 64, 50, 1, 0, 63, 64),                      # W = 1 (<= 64)
+    (100, 128, 65, 90, 20, 127),                         # W = 2
+    (130, 192, 150, 7),                                  # W = 3
+    (200, 256, 230, 31, 255),                            # W = 4
+    (300, 384, 350, 2),                                  # W = 6
+    (500, 512, 450, 64, 0),                              # W = 8
+    (566, 567, 520, 566, 12),                            # W = 9: the length of the bundled HA sequences
+    (700, 768, 650),                                     # W = 12
+    (1000, 1024, 900, 33),                               # W = 16
+])
+def test_nw_long_sequences_match_oracle(da, lengths):
+    """wavefront-per-pair anti-diagonal kernel (k_nw_long): ragged lengths, every column-per-lane width"""
+    rng = np.random.RandomState(sum(lengths))
+    seqs = _rand_seqs(rng, lengths)
+    seqs.append(seqs[0])                                  # an exact duplicate
+    mutated = list(seqs[1])
+    for k in range(0, len(mutated), 7):
+        mutated[k] = "W"
+    seqs.append("".join(mutated[: max(1, len(mutated) - 3)]))   # near duplicate with a length change -> gaps
+    rc, omt, oln, osc, _ = O.nw_rows(seqs)
+    assert rc == 0
+    mt, ln, sc = da.nw_pairs(seqs)
+    assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc)
+    rc, want, _ = O.similarity_nw(seqs)
+    assert_same_f64(da.similarityNW(seqs), want)
+    mt2, ln2, sc2 = da.nw_pairs(seqs, row_begin=1, row_end=len(seqs) - 1)       # row-block path
+    assert np.array_equal(mt2, omt[1:-1]) and np.array_equal(ln2, oln[1:-1]) and np.array_equal(sc2, osc[1:-1])
+
+
+def test_nw_long_other_matrices_and_gaps(da):
+    rng = np.random.RandomState(8)
+    seqs = _rand_seqs(rng, (120, 80, 200, 150, 90), "AGW") + _rand_seqs(rng, (140, 60))
+    for name, go, ge in (("BLOSUM45", 10, 4), ("BLOSUM100", 3, 1), ("BLOSUM62", 0, 0), ("BLOSUM80", 25, 9)):
+        rc, omt, oln, osc, _ = O.nw_rows(seqs, 0, None, name, go, ge)
+        mt, ln, sc = da.nw_pairs(seqs, name, go, ge)
+        assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc), (name, go, ge)
+
+
+def test_nw_too_long_sequences_fail_loudly(da):
     with pytest.raises(da.DynaAlignError) as ei:
-        da.similarityNW(["A" * 40, "C" * 10])
-    assert ei.value.code == 10 and "32" in str(ei.value)
+        da.similarityNW(["A" * 1025, "C" * 10])
+    assert ei.value.code == 10 and "1024" in str(ei.value)
 
 
 # ---------------------------------------------------------------- BASELINE sizes (properties)
@@ -277,3 +320,50 @@ def test_nw_10k_sampled_rows(da):
         rc, mt, ln, sc, _ = O.nw_rows(seqs, r0, r0 + 10)
         assert rc == 0
         assert_same_f64(W[r0:r0 + 10], mt / ln.astype(np.float64))
+
+
+def test_100k_headline_workload_properties(da):
+    """configs[3] (the bench workload): 100 000 h3n2-like 20-mers through the device API, everything
+    resident in HBM.  Whole-matrix properties + oracle compares on row samples; torch is used only
+    to reduce/compare on the device (checker side)."""
+    import torch
+    from dynaalign_amd import device, synth, _capi
+    n, n_hash = 100000, 500
+    res, off = synth.h3n2_like(n, 20)
+    seqs = synth.to_strings(res, off)
+    seeds = da.hash_family_seeds(12345, n_hash)
+    ds = device.DeviceSequences(res, off)
+    sig, planes = device.minhash_signatures(ds, 4, n_hash, seeds)
+    sig_h = sig[:, :n_hash].cpu().numpy().view(np.uint32)
+    for r0 in (0, 31337, 99900):                                   # bit-exact signatures on samples
+        assert np.array_equal(sig_h[r0:r0 + 50], O.signatures(seqs[r0:r0 + 50], 4, n_hash, seeds))
+    cnt = device.mh_compare(planes, n, n_hash, kind=_capi.DA_OUT_COMPACT)          # int16 tensor, 20 GB
+    # sum of all match counts without walking pairs: sum_h sum_v multiplicity(v in column h)^2
+    want_total = 0
+    for h in range(n_hash):
+        _, c = np.unique(sig_h[:, h], return_counts=True)
+        want_total += int((c.astype(np.int64) ** 2).sum())
+    got_total = 0
+    for r0 in range(0, n, 10000):
+        got_total += int(cnt[r0:r0 + 10000].to(torch.int32).sum(dtype=torch.int64).item())
+    assert got_total == want_total
+    assert bool((torch.diagonal(cnt) == n_hash).all())
+    for (a, b) in ((0, 70000), (12800, 12928), (99000, 500)):      # symmetry on sampled blocks
+        assert torch.equal(cnt[a:a + 900, b:b + 900], cnt[b:b + 900, a:a + 900].T)
+    for r0 in (0, 49999, 99980):                                   # oracle compare on row samples
+        want = np.stack([(sig_h[i][None, :] == sig_h).sum(1) for i in range(r0, r0 + 12)]).astype(np.int16)
+        assert np.array_equal(cnt[r0:r0 + 12].cpu().numpy(), want)
+    out = device.mh_compare(planes, n, n_hash, kind=_capi.DA_OUT_F64)              # float64, 80 GB
+    for r0 in range(0, n, 5000):                                   # f64 matrix == counts / n_hash everywhere
+        assert torch.equal(out[r0:r0 + 5000], cnt[r0:r0 + 5000].to(torch.float64) / n_hash)
+    del cnt
+    # NW on the same set: sampled rows against the oracle, symmetry, diagonal
+    assert int(device.nw_encode(ds).item()) == 0
+    device.nw(ds, out=out)
+    assert bool((torch.diagonal(out) == 1.0).all())
+    for (a, b) in ((0, 70000), (6400, 6464), (99000, 500)):
+        assert torch.equal(out[a:a + 900, b:b + 900], out[b:b + 900, a:a + 900].T)
+    for r0 in (0, 50001, 99995):
+        rc, mt, ln, _, _ = O.nw_rows(seqs, r0, r0 + 4)
+        assert rc == 0
+        assert_same_f64(out[r0:r0 + 4].cpu().numpy(), mt / ln.astype(np.float64))
