@@ -354,8 +354,9 @@ def test_100k_headline_workload_properties(da):
         want = np.stack([(sig_h[i][None, :] == sig_h).sum(1) for i in range(r0, r0 + 12)]).astype(np.int16)
         assert np.array_equal(cnt[r0:r0 + 12].cpu().numpy(), want)
     out = device.mh_compare(planes, n, n_hash, kind=_capi.DA_OUT_F64)              # float64, 80 GB
+    ratio = torch.from_numpy(np.arange(n_hash + 1, dtype=np.float64) / n_hash).cuda()   # host IEEE divide
     for r0 in range(0, n, 5000):                                   # f64 matrix == counts / n_hash everywhere
-        assert torch.equal(out[r0:r0 + 5000], cnt[r0:r0 + 5000].to(torch.float64) / n_hash)
+        assert torch.equal(out[r0:r0 + 5000], ratio[cnt[r0:r0 + 5000].long()])
     del cnt
     # NW on the same set: sampled rows against the oracle, symmetry, diagonal
     assert int(device.nw_encode(ds).item()) == 0
