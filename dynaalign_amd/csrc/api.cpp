@@ -5,6 +5,7 @@
 // deliberately NO CPU implementation of the hot path in this library.
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -292,6 +293,137 @@ int da_dev_finalize_shards(const uint16_t *d_gathered, int64_t ld_g, int64_t n, 
   if (!d_gathered || !d_out || world <= 0 || ld_g < n || ld_out < n) return fail(DA_ERR_BAD_ARG, "bad finalize arguments");
   return launch_finalize_sharded(d_gathered, ld_g, n, world, is_nw ? 64 : 128, da_shard_rows(n, world, is_nw), is_nw != 0,
                                  n_hash, d_out, ld_out, static_cast<hipStream_t>(stream));
+}
+
+
+// ---- threshold + sparsify: the step clusterbreak applies right after sim_fn -------------
+
+int da_dev_upper_histogram(const uint16_t *d_compact, int64_t ld, int64_t n, int nbins, uint64_t *d_hist, void *stream) {
+  if (n <= 0) return DA_OK;
+  if (!d_compact || !d_hist || ld < n || nbins <= 0 || nbins > 65536) return fail(DA_ERR_BAD_ARG, "bad histogram arguments");
+  return launch_upper_histogram(d_compact, ld, n, nbins, reinterpret_cast<unsigned long long *>(d_hist),
+                                static_cast<hipStream_t>(stream));
+}
+
+int da_dev_extract_edges(const uint16_t *d_compact, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,
+                         int include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
+                         uint64_t *d_count, void *stream) {
+  if (n <= 0) return DA_OK;
+  if (!d_compact || !d_keep || !d_i || !d_j || !d_v || !d_count || ld < n || nbins <= 0 || nbins > 65536 || capacity < 0)
+    return fail(DA_ERR_BAD_ARG, "bad edge-extraction arguments");
+  if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "edge indices are int32");
+  return launch_extract_edges(d_compact, ld, n, d_keep, nbins, include_diagonal != 0, d_i, d_j, d_v, capacity,
+                              reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream));
+}
+
+// R's quantile(x, p, type = 7) (stats::quantile.default, the default the reference's
+// R/clusterbreak.R:219 uses) of the multiset {values[b] x hist[b]}, values ascending:
+//   index = 1 + (N-1) p; lo = floor(index); hi = ceiling(index); q = x[lo];
+//   if (index > lo && x[hi] != q) q = (1-h) q + h x[hi],  h = index - lo
+int da_quantile_type7(const uint64_t *hist, const double *values, int nbins, double p, double *q_out) {
+  if (!hist || !values || !q_out || nbins <= 0 || !(p >= 0.0 && p <= 1.0)) return fail(DA_ERR_BAD_ARG, "bad quantile arguments");
+  uint64_t total = 0;
+  for (int b = 0; b < nbins; ++b) total += hist[b];
+  if (total == 0) return fail(DA_ERR_BAD_ARG, "quantile of an empty set");
+  const double index = 1.0 + (double)(total - 1) * p;
+  const double lo = std::floor(index), hi = std::ceil(index);
+  auto at = [&](double pos1) {  // pos1: 1-based rank
+    const uint64_t r = (uint64_t)pos1;
+    uint64_t cum = 0;
+    for (int b = 0; b < nbins; ++b) {
+      cum += hist[b];
+      if (r <= cum) return values[b];
+    }
+    return values[nbins - 1];
+  };
+  double q = at(lo);
+  const double xh = at(hi);
+  if (index > lo && xh != q) {
+    const double h = index - lo;
+    q = (1.0 - h) * q + h * xh;
+  }
+  *q_out = q;
+  return DA_OK;
+}
+
+int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                           const uint32_t *seeds, double thresh_p, double *threshold_out, int64_t *n_edges_out,
+                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+  int rc = validate_mh(n, k, n_hash);
+  if (rc != DA_OK) return rc;
+  if (!residues || !seeds || !threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (n < 2) return fail(DA_ERR_BAD_ARG, "the threshold is a quantile of the strict upper triangle: need >= 2 sequences");
+  if (!(thresh_p >= 0.0 && thresh_p <= 1.0)) return fail(DA_ERR_BAD_ARG, "thresh_p must be in [0, 1]");
+  if (n_hash > 65535) return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
+  int64_t total, max_len;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  if ((rc = require_device()) != DA_OK) return rc;
+  DeviceInput in;
+  if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
+  const int64_t lds = sig_ld_for(n_hash), ldp = 2 * lds;
+  DevBuf sig, planes, cnt, hist, keep, cnt_edges;
+  if ((rc = sig.alloc((size_t)n * lds * 4)) != DA_OK) return rc;
+  if ((rc = planes.alloc((size_t)n * ldp * 4)) != DA_OK) return rc;
+  if ((rc = cnt.alloc((size_t)n * (size_t)n * 2)) != DA_OK) return rc;   // uint16 counts stay on the device
+  const int nbins = n_hash + 1;
+  if ((rc = hist.alloc((size_t)nbins * 8)) != DA_OK) return rc;
+  DA_HIP_TRY(hipMemset(hist.p, 0, (size_t)nbins * 8));
+  if ((rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash, in.seeds.as<uint32_t>(),
+                                      sig.as<uint32_t>(), lds, planes.as<uint32_t>(), ldp, nullptr)) != DA_OK) return rc;
+  if ((rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, DA_OUT_COMPACT, cnt.p, n, nullptr)) != DA_OK)
+    return rc;
+  if ((rc = launch_upper_histogram(cnt.as<uint16_t>(), n, n, nbins, hist.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
+  std::vector<uint64_t> h(nbins);
+  DA_HIP_TRY(hipMemcpy(h.data(), hist.p, (size_t)nbins * 8, hipMemcpyDeviceToHost));
+  std::vector<double> values(nbins);
+  for (int b = 0; b < nbins; ++b) values[b] = (double)b / n_hash;          // src/minHash.cpp:174
+  double thr;
+  if ((rc = da_quantile_type7(h.data(), values.data(), nbins, thresh_p, &thr)) != DA_OK) return rc;
+  *threshold_out = thr;
+  // pep.sim[pep.sim < threshold] <- 0 (R/clusterbreak.R:221); a zero weight is no edge (igraph, weighted = TRUE)
+  std::vector<uint8_t> kp(nbins);
+  int64_t n_edges = n;                                                       // the diagonal (1.0) always survives
+  for (int b = 0; b < nbins; ++b) {
+    kp[b] = (b != 0 && !(values[b] < thr)) ? 1 : 0;
+    if (kp[b]) n_edges += (int64_t)h[b];
+  }
+  *n_edges_out = n_edges;
+  if (!ei && !ej && !ew) return DA_OK;                                       // size query
+  if (!ei || !ej || !ew) return fail(DA_ERR_BAD_ARG, "NULL edge buffer");
+  if (capacity < n_edges) return fail(DA_ERR_BAD_ARG, "edge buffers hold %lld entries, %lld needed", (long long)capacity,
+                                      (long long)n_edges);
+  if (n_edges == 0) return DA_OK;
+  DevBuf di, dj, dv;
+  if ((rc = keep.alloc((size_t)nbins)) != DA_OK) return rc;
+  if ((rc = cnt_edges.alloc(8)) != DA_OK) return rc;
+  if ((rc = di.alloc((size_t)n_edges * 4)) != DA_OK) return rc;
+  if ((rc = dj.alloc((size_t)n_edges * 4)) != DA_OK) return rc;
+  if ((rc = dv.alloc((size_t)n_edges * 2)) != DA_OK) return rc;
+  DA_HIP_TRY(hipMemcpy(keep.p, kp.data(), (size_t)nbins, hipMemcpyHostToDevice));
+  DA_HIP_TRY(hipMemset(cnt_edges.p, 0, 8));
+  if ((rc = launch_extract_edges(cnt.as<uint16_t>(), n, n, keep.as<uint8_t>(), nbins, true, di.as<int32_t>(), dj.as<int32_t>(),
+                                 dv.as<uint16_t>(), n_edges, cnt_edges.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
+  uint64_t got = 0;
+  DA_HIP_TRY(hipMemcpy(&got, cnt_edges.p, 8, hipMemcpyDeviceToHost));
+  if ((int64_t)got != n_edges) return fail(DA_ERR_HIP, "edge count mismatch: histogram says %lld, extraction found %llu",
+                                           (long long)n_edges, (unsigned long long)got);
+  std::vector<int32_t> hi_(n_edges), hj_(n_edges);
+  std::vector<uint16_t> hv_(n_edges);
+  DA_HIP_TRY(hipMemcpy(hi_.data(), di.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost));
+  DA_HIP_TRY(hipMemcpy(hj_.data(), dj.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost));
+  DA_HIP_TRY(hipMemcpy(hv_.data(), dv.p, (size_t)n_edges * 2, hipMemcpyDeviceToHost));
+  // the device appends in arrival order; hand the edges back sorted by (i, j)
+  std::vector<int64_t> order(n_edges);
+  for (int64_t e = 0; e < n_edges; ++e) order[e] = e;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+    return hi_[a] != hi_[b] ? hi_[a] < hi_[b] : hj_[a] < hj_[b];
+  });
+  for (int64_t e = 0; e < n_edges; ++e) {
+    ei[e] = hi_[order[e]];
+    ej[e] = hj_[order[e]];
+    ew[e] = values[hv_[order[e]]];
+  }
+  return DA_OK;
 }
 
 int64_t da_sig_ld(int n_hash) { return sig_ld_for(n_hash); }

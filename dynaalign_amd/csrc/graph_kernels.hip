@@ -1,0 +1,128 @@
+// graph_kernels.hip -- the step right after the hot path in the reference's caller:
+//
+//   threshold <- quantile(pep.sim[upper.tri(pep.sim)], thresh_p)        R/clusterbreak.R:219
+//   pep.sim[pep.sim < threshold] <- 0                                   R/clusterbreak.R:221
+//   graph_from_adjacency_matrix(pep.sim, mode = "upper", weighted = TRUE)   R/clusterbreak.R:122-124
+//
+// MinHash similarities take only n_hash+1 distinct values (count / n_hash), so a histogram of the
+// match counts of the strict upper triangle gives R's type-7 quantile EXACTLY, and only the
+// surviving entries need to leave the GPU -- as an edge list instead of an 80 GB dense matrix
+// (SURVEY 8(f)-1).  Both kernels stream the compact uint16 count matrix K2 produces (HBM-bound).
+#include "da_common.hpp"
+
+namespace da {
+namespace {
+
+constexpr int G_TILE = 128;
+constexpr int G_THREADS = 256;
+constexpr int G_LDS_BINS = 4096;
+
+// upper-triangular 128x128 tile id -> (ti, tj), row-major over the triangle
+__device__ __forceinline__ void tri_tile(int64_t L, int T, int &ti, int &tj) {
+  const double Td = (double)T;
+  int64_t t = (int64_t)(Td + 0.5 - sqrt((Td + 0.5) * (Td + 0.5) - 2.0 * (double)L));
+  if (t < 0) t = 0;
+  if (t > T - 1) t = T - 1;
+  auto start = [&](int64_t r) { return r * T - r * (r - 1) / 2; };
+  while (t > 0 && start(t) > L) --t;
+  while (t + 1 <= T - 1 && start(t + 1) <= L) ++t;
+  ti = (int)t;
+  tj = (int)(t + (L - start(t)));
+}
+
+// hist[v] += number of pairs i < j with m[i][j] == v
+__global__ __launch_bounds__(G_THREADS) void k_upper_histogram(const uint16_t *__restrict__ m, int64_t ld, int64_t n,
+                                                               int nbins, unsigned long long *__restrict__ hist, int T) {
+  __shared__ unsigned int lh[G_LDS_BINS];
+  const bool use_lds = nbins <= G_LDS_BINS;
+  if (use_lds)
+    for (int b = threadIdx.x; b < nbins; b += G_THREADS) lh[b] = 0;
+  __syncthreads();
+  int ti, tj;
+  tri_tile(blockIdx.x, T, ti, tj);
+  const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
+  const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;  // 128 columns x 2 rows per pass
+  const int64_t j = J0 + cx;
+  for (int r = ry; r < G_TILE; r += 2) {
+    const int64_t i = I0 + r;
+    if (i < n && j < n && j > i) {
+      const unsigned v = m[i * ld + j];
+      if (v < (unsigned)nbins) {
+        if (use_lds) atomicAdd(&lh[v], 1u);
+        else atomicAdd(&hist[v], 1ull);
+      }
+    }
+  }
+  __syncthreads();
+  if (use_lds)
+    for (int b = threadIdx.x; b < nbins; b += G_THREADS)
+      if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
+// append (i, j, v) for every i <= j (diagonal optional) whose value v is flagged in keep[]
+__global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__restrict__ m, int64_t ld, int64_t n,
+                                                             const uint8_t *__restrict__ keep, int nbins,
+                                                             int include_diagonal, int32_t *__restrict__ ei,
+                                                             int32_t *__restrict__ ej, uint16_t *__restrict__ ev,
+                                                             long long capacity, unsigned long long *__restrict__ count,
+                                                             int T) {
+  int ti, tj;
+  tri_tile(blockIdx.x, T, ti, tj);
+  const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
+  const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;
+  const int lane = threadIdx.x & 63;
+  const int64_t j = J0 + cx;
+  for (int r = ry; r < G_TILE; r += 2) {
+    const int64_t i = I0 + r;
+    bool take = false;
+    unsigned v = 0;
+    if (i < n && j < n && (j > i || (include_diagonal && j == i))) {
+      v = m[i * ld + j];
+      take = v < (unsigned)nbins && keep[v] != 0;
+    }
+    // one atomic per wavefront: reserve a run of slots, lanes fill it in lane order
+    const unsigned long long mask = __ballot(take);
+    if (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
+      base = __shfl(base, leader);
+      if (take) {
+        const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if ((long long)slot < capacity) {
+          ei[slot] = (int32_t)i;
+          ej[slot] = (int32_t)j;
+          ev[slot] = (uint16_t)v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
+                           hipStream_t stream) {
+  if (n <= 1) return DA_OK;
+  const int T = (int)ceil_div(n, G_TILE);
+  const int64_t tiles = (int64_t)T * (T + 1) / 2;
+  if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
+  hipLaunchKernelGGL(k_upper_histogram, dim3((unsigned)tiles), dim3(G_THREADS), 0, stream, d_m, ld, n, nbins, d_hist, T);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,
+                         bool include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
+                         unsigned long long *d_count, hipStream_t stream) {
+  if (n <= 0) return DA_OK;
+  const int T = (int)ceil_div(n, G_TILE);
+  const int64_t tiles = (int64_t)T * (T + 1) / 2;
+  if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
+  hipLaunchKernelGGL(k_extract_edges, dim3((unsigned)tiles), dim3(G_THREADS), 0, stream, d_m, ld, n, d_keep, nbins,
+                     include_diagonal ? 1 : 0, d_i, d_j, d_v, (long long)capacity, d_count, T);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+}  // namespace da

@@ -136,3 +136,26 @@ def widen(compact, is_nw, n_hash=0, out=None):
     _capi.check(_capi.load().da_dev_widen(compact.data_ptr(), out.data_ptr(), compact.numel(), 1 if is_nw else 0,
                                           int(n_hash), _stream()))
     return out
+
+
+def upper_histogram(compact, n, nbins):
+    """uint64 histogram (int64 tensor) of the strict upper triangle of an n x n uint16 count matrix."""
+    hist = torch.zeros(nbins, dtype=torch.int64, device=compact.device)
+    _capi.check(_capi.load().da_dev_upper_histogram(compact.data_ptr(), compact.stride(0), n, int(nbins),
+                                                    hist.data_ptr(), _stream()))
+    return hist
+
+
+def extract_edges(compact, n, keep, capacity, include_diagonal=True):
+    """Append (i, j, value) of the upper-triangle entries whose value v has keep[v] != 0.
+    Returns (i, j, v, count): int32, int32, int16 tensors of `capacity` slots and the int64 count tensor."""
+    dev = compact.device
+    keep_t = torch.as_tensor(np.ascontiguousarray(keep, np.uint8)).to(dev)
+    ei = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    ej = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    ev = torch.empty(max(capacity, 1), dtype=torch.int16, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    _capi.check(_capi.load().da_dev_extract_edges(compact.data_ptr(), compact.stride(0), n, keep_t.data_ptr(),
+                                                  keep_t.numel(), 1 if include_diagonal else 0, ei.data_ptr(),
+                                                  ej.data_ptr(), ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream()))
+    return ei, ej, ev, cnt

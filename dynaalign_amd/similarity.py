@@ -168,3 +168,37 @@ def nw_pairs(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4, *, row_begi
                                 _as_int(gapExt, "gapExt"), row_begin, row_end, mt.ctypes.data, ln.ctypes.data,
                                 sc.ctypes.data))
     return mt[:r, :n], ln[:r, :n], sc[:r, :n]
+
+
+def quantile_type7(hist, values, p):
+    """R's quantile(x, p, type = 7) of {values[b] repeated hist[b] times} (values ascending)."""
+    lib = _capi.load()
+    h = np.ascontiguousarray(hist, np.uint64)
+    v = np.ascontiguousarray(values, np.float64)
+    q = np.zeros(1, np.float64)
+    _capi.check(lib.da_quantile_type7(h.ctypes.data, v.ctypes.data, len(h), float(p), q.ctypes.data))
+    return float(q[0])
+
+
+def similarityMH_edges(sequences, k=4, n_hash=50, thresh_p=0.8, *, seed=None):
+    """similarityMH followed by clusterbreak's threshold step, fused on the device.
+
+    Equivalent to (reference R/clusterbreak.R:217-221, netcluster :122-124)
+
+        S <- similarityMH(sequences, k, n_hash)
+        threshold <- quantile(S[upper.tri(S)], thresh_p)
+        S[S < threshold] <- 0                      # edges = non-zero entries of the upper triangle + diagonal
+
+    but returns only ``(threshold, i, j, weight)`` -- the surviving entries with i <= j (0-based, sorted),
+    never the dense matrix."""
+    lib, res, off, n, k, n_hash, seeds = _mh_prelude(sequences, k, n_hash, seed)
+    thr = np.zeros(1, np.float64)
+    cnt = np.zeros(1, np.int64)
+    _capi.check(lib.da_similarity_mh_edges(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
+                                           float(thresh_p), thr.ctypes.data, cnt.ctypes.data, 0, None, None, None))
+    m = int(cnt[0])
+    ei, ej, ew = np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.float64)
+    _capi.check(lib.da_similarity_mh_edges(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
+                                           float(thresh_p), thr.ctypes.data, cnt.ctypes.data, m, ei.ctypes.data,
+                                           ej.ctypes.data, ew.ctypes.data))
+    return float(thr[0]), ei[:m], ej[:m], ew[:m]

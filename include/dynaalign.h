@@ -192,6 +192,32 @@ int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n,
 int da_dev_finalize_shards(const uint16_t *d_gathered, int64_t ld_g, int64_t n, int world,
                            int is_nw, int n_hash, double *d_out, int64_t ld_out, void *stream);
 
+/* ---- threshold + sparsify: what clusterbreak does right after sim_fn ---------
+ * reference R/clusterbreak.R:219-221 (+ netcluster's graph_from_adjacency_matrix
+ * mode = "upper", :122-124):
+ *     threshold <- quantile(pep.sim[upper.tri(pep.sim)], thresh_p)      (R type 7)
+ *     pep.sim[pep.sim < threshold] <- 0
+ * MinHash similarities take n_hash+1 distinct values, so a device-side histogram
+ * of the match counts yields that quantile exactly and only the surviving
+ * upper-triangle entries (i <= j, diagonal = 1.0 included; zero weights are no
+ * edges) leave the GPU, as a (i, j, weight) list sorted by (i, j), 0-based.
+ * Call with ei = ej = ew = NULL to obtain threshold and edge count first. */
+int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                           int k, int n_hash, const uint32_t *seeds, double thresh_p,
+                           double *threshold_out, int64_t *n_edges_out,
+                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew);
+/* R's quantile(x, p, type = 7) of the multiset {values[b] repeated hist[b] times},
+ * values ascending (host arithmetic, no device needed). */
+int da_quantile_type7(const uint64_t *hist, const double *values, int nbins, double p, double *q_out);
+/* device pieces: histogram of the strict upper triangle of an n x n uint16 matrix
+ * (caller zeroes d_hist[nbins]); append of entries flagged in d_keep[nbins]
+ * (caller zeroes *d_count; entries beyond `capacity` are counted, not stored). */
+int da_dev_upper_histogram(const uint16_t *d_compact, int64_t ld, int64_t n, int nbins,
+                           uint64_t *d_hist, void *stream);
+int da_dev_extract_edges(const uint16_t *d_compact, int64_t ld, int64_t n, const uint8_t *d_keep,
+                         int nbins, int include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v,
+                         int64_t capacity, uint64_t *d_count, void *stream);
+
 /* name -> id for da_dev_nw; -1 + DA_ERR_BAD_MATRIX message when unknown. */
 int da_matrix_id(const char *matrix_name);
 

@@ -111,3 +111,29 @@ NumericMatrix similarityNW(CharacterVector sequences, std::string matrixName = "
   set_dimnames(out);
   return out;
 }
+
+//' @name similarityMH_edges
+//' @title MinHash similarity + clusterbreak's quantile threshold, as an edge list
+//' @description Non-breaking addition.  Equivalent to
+//'   S <- similarityMH(sequences, k, n_hash); thr <- quantile(S[upper.tri(S)], thresh_p); S[S < thr] <- 0
+//' (R/clusterbreak.R:217-221) but returns only the surviving upper-triangle entries, so a 100k-peptide set
+//' never materialises its 80 GB matrix:  igraph::graph_from_data_frame(res$edges, directed = FALSE).
+//' @export
+// [[Rcpp::export]]
+List similarityMH_edges(CharacterVector sequences, int k = 4, int n_hash = 50, double thresh_p = 0.8) {
+  const Packed in(sequences);
+  const int64_t n = sequences.length();
+  std::vector<uint32_t> seeds(n_hash > 0 ? n_hash : 1);
+  if (n_hash > 0) check(da_hash_family_seeds(hash_seed(), n_hash, seeds.data()));
+  double thr = 0;
+  int64_t m = 0;
+  check(da_similarity_mh_edges(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), thresh_p, &thr, &m, 0,
+                               nullptr, nullptr, nullptr));
+  IntegerVector from(m), to(m);
+  NumericVector weight(m);
+  check(da_similarity_mh_edges(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), thresh_p, &thr, &m, m,
+                               INTEGER(from), INTEGER(to), REAL(weight)));
+  for (int64_t e = 0; e < m; ++e) { from[e] += 1; to[e] += 1; }   // R is 1-based
+  return List::create(_["threshold"] = thr,
+                      _["edges"] = DataFrame::create(_["from"] = from, _["to"] = to, _["weight"] = weight));
+}
