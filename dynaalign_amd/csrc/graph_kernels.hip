@@ -59,42 +59,55 @@ __global__ __launch_bounds__(G_THREADS) void k_upper_histogram(const uint16_t *_
       if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
 }
 
-// append (i, j, v) for every i <= j (diagonal optional) whose value v is flagged in keep[]
+// append (i, j, v) for every i <= j (diagonal optional) whose value v is flagged in keep[].
+// One global atomic per 128x128 tile (a single counter word saturates near 90 atomics/us, so
+// per-wave reservations -- 78 M of them at N = 100k -- would serialise the whole kernel):
+// every thread scans its column strip, the workgroup scans the per-thread counts in LDS, one
+// lane reserves the tile's run of slots, threads then write their own contiguous sub-runs.
 __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__restrict__ m, int64_t ld, int64_t n,
                                                              const uint8_t *__restrict__ keep, int nbins,
                                                              int include_diagonal, int32_t *__restrict__ ei,
                                                              int32_t *__restrict__ ej, uint16_t *__restrict__ ev,
                                                              long long capacity, unsigned long long *__restrict__ count,
                                                              int T) {
+  __shared__ unsigned int scan[G_THREADS];
+  __shared__ unsigned long long tile_base;
   int ti, tj;
   tri_tile(blockIdx.x, T, ti, tj);
   const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
-  const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;
-  const int lane = threadIdx.x & 63;
+  const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;   // column cx, rows ry, ry+2, ...
   const int64_t j = J0 + cx;
-  for (int r = ry; r < G_TILE; r += 2) {
-    const int64_t i = I0 + r;
-    bool take = false;
-    unsigned v = 0;
+  unsigned long long kept = 0;                               // bit q <-> row ry + 2q
+  for (int q = 0; q < G_TILE / 2; ++q) {
+    const int64_t i = I0 + ry + 2 * q;
     if (i < n && j < n && (j > i || (include_diagonal && j == i))) {
-      v = m[i * ld + j];
-      take = v < (unsigned)nbins && keep[v] != 0;
+      const unsigned v = m[i * ld + j];
+      if (v < (unsigned)nbins && keep[v] != 0) kept |= 1ull << q;
     }
-    // one atomic per wavefront: reserve a run of slots, lanes fill it in lane order
-    const unsigned long long mask = __ballot(take);
-    if (mask) {
-      const int leader = __ffsll((long long)mask) - 1;
-      unsigned long long base = 0;
-      if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
-      base = __shfl(base, leader);
-      if (take) {
-        const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if ((long long)slot < capacity) {
-          ei[slot] = (int32_t)i;
-          ej[slot] = (int32_t)j;
-          ev[slot] = (uint16_t)v;
-        }
+  }
+  const unsigned mine = (unsigned)__popcll(kept);
+  scan[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < G_THREADS; off <<= 1) {            // inclusive Hillis-Steele scan (256 entries)
+    const unsigned add = threadIdx.x >= (unsigned)off ? scan[threadIdx.x - off] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const unsigned total = scan[G_THREADS - 1];
+  if (total == 0) return;
+  if (threadIdx.x == 0) tile_base = atomicAdd(count, (unsigned long long)total);
+  __syncthreads();
+  unsigned long long slot = tile_base + (scan[threadIdx.x] - mine);
+  for (int q = 0; q < G_TILE / 2; ++q) {
+    if (kept & (1ull << q)) {
+      const int64_t i = I0 + ry + 2 * q;
+      if ((long long)slot < capacity) {
+        ei[slot] = (int32_t)i;
+        ej[slot] = (int32_t)j;
+        ev[slot] = m[i * ld + j];
       }
+      ++slot;
     }
   }
 }
