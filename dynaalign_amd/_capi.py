@@ -46,6 +46,7 @@ SIGNATURES = {
     "da_dev_extract_edges": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "da_matrix_id": (_i32, [C.c_char_p]),
     "da_shard_rows": (_i64, [_i64, _i32, _i32]),
+    "da_shard_ld": (_i64, [_i64, _i32, _i32]),
     "da_dev_mh_compare_shard": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_shard": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_finalize_shards": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),

@@ -260,9 +260,12 @@ int da_dev_widen(const uint16_t *d_in, double *d_out, int64_t count, int is_nw, 
 // ---- row-sharding over `world` ranks: rank p owns tile rows p, p+world, ... (cyclic, so
 // the upper-triangular work is balanced); tile = 128 rows for MH, 64 for NW.
 int64_t da_shard_rows(int64_t n, int world, int is_nw) {
-  const int64_t tile = is_nw ? 64 : 128;
   if (n <= 0 || world <= 0) return 0;
-  return ceil_div(ceil_div(n, tile), world) * tile;
+  return shard_geom(n, world, is_nw ? 64 : 128).rows;
+}
+int64_t da_shard_ld(int64_t n, int world, int is_nw) {
+  if (n <= 0 || world <= 0) return 0;
+  return shard_geom(n, world, is_nw ? 64 : 128).W;
 }
 
 int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash, int rank,
@@ -270,19 +273,22 @@ int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int64_t
   if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
   if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
   if (n_hash > 65535) return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
-  if (!d_planes || !d_local || world <= 0 || rank < 0 || rank >= world || ld < n) return fail(DA_ERR_BAD_ARG, "bad shard arguments");
+  if (!d_planes || !d_local || world <= 0 || rank < 0 || rank >= world) return fail(DA_ERR_BAD_ARG, "bad shard arguments");
+  const ShardGeom sg = shard_geom(n, world, 128);
+  if (ld < sg.W) return fail(DA_ERR_BAD_ARG, "ld (%lld) < da_shard_ld (%lld)", (long long)ld, (long long)sg.W);
   if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
     return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
   if ((int64_t)rank * 128 >= n) return DA_OK;  // this rank owns no rows
   return launch_mh_compare(d_planes, ld_planes, n, n_hash, (int64_t)rank * 128, n, false, DA_OUT_COMPACT, d_local, ld,
-                           static_cast<hipStream_t>(stream), world, true);
+                           static_cast<hipStream_t>(stream), world, true, sg.Q, sg.W);
 }
 
 int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len, int matrix_id,
                     int gap_open, int gap_ext, int rank, int world, uint16_t *d_local, int64_t ld, void *stream) {
   if (n <= 0) return DA_OK;
-  if (!d_codes || !d_offsets || !d_local || world <= 0 || rank < 0 || rank >= world || ld < n)
+  if (!d_codes || !d_offsets || !d_local || world <= 0 || rank < 0 || rank >= world)
     return fail(DA_ERR_BAD_ARG, "bad shard arguments");
+  if (ld < shard_geom(n, world, 64).W) return fail(DA_ERR_BAD_ARG, "ld < da_shard_ld");
   return launch_nw(d_codes, d_offsets, n, max_len, matrix_id, gap_open, gap_ext, 0, n, false, DA_OUT_COMPACT, d_local, ld,
                    nullptr, 0, static_cast<hipStream_t>(stream), rank, world);
 }
@@ -290,9 +296,10 @@ int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n,
 int da_dev_finalize_shards(const uint16_t *d_gathered, int64_t ld_g, int64_t n, int world, int is_nw, int n_hash,
                            double *d_out, int64_t ld_out, void *stream) {
   if (n <= 0) return DA_OK;
-  if (!d_gathered || !d_out || world <= 0 || ld_g < n || ld_out < n) return fail(DA_ERR_BAD_ARG, "bad finalize arguments");
-  return launch_finalize_sharded(d_gathered, ld_g, n, world, is_nw ? 64 : 128, da_shard_rows(n, world, is_nw), is_nw != 0,
-                                 n_hash, d_out, ld_out, static_cast<hipStream_t>(stream));
+  if (!d_gathered || !d_out || world <= 0 || ld_out < n) return fail(DA_ERR_BAD_ARG, "bad finalize arguments");
+  const ShardGeom sg = shard_geom(n, world, is_nw ? 64 : 128);
+  if (ld_g < sg.W) return fail(DA_ERR_BAD_ARG, "ld_g < da_shard_ld");
+  return launch_finalize_sharded(d_gathered, ld_g, sg, is_nw != 0, n_hash, d_out, ld_out, static_cast<hipStream_t>(stream));
 }
 
 

@@ -30,6 +30,26 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Folded layout of one rank's shard (row-sharded multi-GPU path).  Rank p owns tile rows
+// t = q*world + p (q = 0..Q-1) and only their part right of the diagonal is valid, so local
+// tile rows q and Q-1-q share one stored tile row of width W = n + world*tile (rounded up to
+// 8): the first left-aligned from its diagonal tile, the second right-aligned.  That halves
+// the bytes the all-gather has to move.
+struct ShardGeom {
+  int64_t n, W, rows;  // rows = local rows per rank
+  int world, tile, T, Q, Qh;
+};
+inline ShardGeom shard_geom(int64_t n, int world, int tile) {
+  ShardGeom g;
+  g.n = n; g.world = world; g.tile = tile;
+  g.T = (int)ceil_div(n, tile);
+  g.Q = (int)ceil_div(g.T, world);
+  g.Qh = (g.Q + 1) / 2;
+  g.W = ceil_div(n + (int64_t)world * tile, 8) * 8;
+  g.rows = (int64_t)g.Qh * tile;
+  return g;
+}
+
 // Kernel launchers implemented in the .hip translation units.  All are
 // asynchronous on `stream`; argument checking is done by the C-ABI layer.
 int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n,
@@ -39,10 +59,9 @@ int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_
 int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
                       void *d_out, int64_t ld, hipStream_t stream, int tile_stride = 1,
-                      bool upper_only = false);
-int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, int64_t n, int world, int tile,
-                            int64_t rows_per_rank, bool is_nw, int n_hash, double *d_out, int64_t ld,
-                            hipStream_t stream);
+                      bool upper_only = false, int fold_q = 0, int64_t fold_w = 0);
+int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
+                            double *d_out, int64_t ld, hipStream_t stream);
 int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,
                      hipStream_t stream);
 int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,

@@ -264,7 +264,7 @@ template <bool SYM, bool F64>
 __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const uint32_t *__restrict__ planes, int64_t ld_p, int64_t n, int n_hash, int64_t row_begin,
     int64_t row_end, int tile_stride, int upper_only, int TR, void *__restrict__ out_v, int64_t ld,
-    int64_t ntiles, int64_t per_xcd) {
+    int64_t ntiles, int64_t per_xcd, int fold_q, int64_t fold_w) {
   // Row-block geometry: local tile row q covers global rows row_begin + q*tile_stride*128 + [0,128)
   // (tile_stride = 1: a contiguous block; = world: the cyclic shard of one rank) and is stored at
   // local rows q*128 + [0,128) of `out`.  upper_only skips tiles left of the diagonal.
@@ -282,7 +282,14 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   if (!tid2.valid) return;
   const int64_t I0 = row_begin + (int64_t)tid2.ti * tile_stride * K2_TILE;  // global row of tile row 0
   const int64_t J0 = (int64_t)tid2.tj * K2_TILE;
-  const int64_t Iloc = (int64_t)tid2.ti * K2_TILE - I0;                     // local row = global row + Iloc
+  int64_t Iloc = (int64_t)tid2.ti * K2_TILE - I0;                           // local row = global row + Iloc
+  int64_t Jloc = 0;                                                         // local col = global col + Jloc
+  if (!SYM && fold_q > 0) {  // folded shard layout (ShardGeom): tile rows q and Q-1-q share a stored row
+    const int q = tid2.ti;
+    const bool front = q <= fold_q - 1 - q;
+    Iloc = (int64_t)(front ? q : fold_q - 1 - q) * K2_TILE - I0;
+    Jloc = front ? -I0 : fold_w - n;
+  }
   if (I0 >= row_end || I0 >= n) return;
   if (!SYM && upper_only && J0 + K2_TILE <= I0) return;                     // tile entirely left of the diagonal
 
@@ -402,12 +409,12 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   // lane's rows: 32*g + 2*ty + e  <-> index r = 2*g + e ; cols likewise.
   if (F64) {
     double *out = reinterpret_cast<double *>(out_v);
-    const bool vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const bool vec_ok = ((ld & 1) == 0) && ((Jloc & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
       if (gi >= row_end || gi >= n) continue;
-      double *orow = out + (gi + Iloc) * ld;
+      double *orow = out + (gi + Iloc) * ld + Jloc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t gj = J0 + 32 * g + 2 * tx;
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     for (int r = 0; r < 8; ++r) {
       const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
       if (gi >= row_end || gi >= n) continue;
-      uint16_t *orow = out + (gi + Iloc) * ld;
+      uint16_t *orow = out + (gi + Iloc) * ld + Jloc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t gj = J0 + 32 * g + 2 * tx;
@@ -518,7 +525,8 @@ int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_
 
 int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
-                      void *d_out, int64_t ld, hipStream_t stream, int tile_stride, bool upper_only) {
+                      void *d_out, int64_t ld, hipStream_t stream, int tile_stride, bool upper_only,
+                      int fold_q, int64_t fold_w) {
   if (row_end <= row_begin) return DA_OK;
   const int T = (int)ceil_div(n, K2_TILE);
   const int TR = (int)ceil_div(ceil_div(row_end - row_begin, K2_TILE), tile_stride);
@@ -529,7 +537,7 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
 #define DA_K2(SYM, F64)                                                                              \
   hipLaunchKernelGGL((k_mh_compare<SYM, F64>), grid, block, 0, stream, d_planes, ld_planes, n, n_hash, \
-                     row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd)
+                     row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w)
   if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true); else DA_K2(true, false); }
   else           { if (kind == DA_OUT_F64) DA_K2(false, true); else DA_K2(false, false); }
 #undef DA_K2
@@ -537,12 +545,12 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
   return DA_OK;
 }
 
-// Gathered shards -> final matrix.  G holds, for every rank p, its local rows (cyclic tile rows
-// p, p+world, ... of `tile` rows each, upper-triangular tiles valid); out[i][j] = widen(G[map(min)][max]).
-__global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__restrict__ G, int64_t ld_g, int64_t n,
-                                                          int world, int tile, int64_t rows_per_rank, int is_nw,
-                                                          int n_hash, double *__restrict__ out, int64_t ld) {
+// Gathered shards -> final matrix.  G holds, for every rank p, its folded local block
+// (ShardGeom); out[i][j] = widen(G[entry of (min(i,j), max(i,j))]).
+__global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__restrict__ G, int64_t ld_g, ShardGeom geom,
+                                                          int is_nw, int n_hash, double *__restrict__ out, int64_t ld) {
   __shared__ uint16_t t[32][33];
+  const int64_t n = geom.n;
   const int64_t bi = blockIdx.y, bj = blockIdx.x;
   if (bj < bi) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -554,10 +562,13 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
   };
   for (int r = ty; r < 32; r += 8) {
     const int64_t i = bi * 32 + r, j = bj * 32 + tx;
-    if (i < n && j < n) {
-      const int64_t tr = i / tile;
-      const int64_t grow = (tr % world) * rows_per_rank + (tr / world) * tile + (i - tr * tile);
-      t[r][tx] = G[grow * ld_g + j];
+    if (i < n && j < n && j >= i) {
+      const int64_t tr = i / geom.tile;                                  // global tile row, owner tr % world
+      const int q = (int)(tr / geom.world);
+      const bool front = q <= geom.Q - 1 - q;
+      const int64_t lrow = (int64_t)(front ? q : geom.Q - 1 - q) * geom.tile + (i - tr * geom.tile);
+      const int64_t lcol = front ? j - tr * geom.tile : geom.W - n + j;
+      t[r][tx] = G[((tr % geom.world) * geom.rows + lrow) * ld_g + lcol];
     }
   }
   __syncthreads();
@@ -571,13 +582,11 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
   }
 }
 
-int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, int64_t n, int world, int tile,
-                            int64_t rows_per_rank, bool is_nw, int n_hash, double *d_out, int64_t ld,
-                            hipStream_t stream) {
-  if (n <= 0) return DA_OK;
-  const unsigned t = (unsigned)ceil_div(n, 32);
-  hipLaunchKernelGGL(k_finalize_sharded, dim3(t, t), dim3(256), 0, stream, d_g, ld_g, n, world, tile, rows_per_rank,
-                     is_nw ? 1 : 0, n_hash, d_out, ld);
+int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
+                            double *d_out, int64_t ld, hipStream_t stream) {
+  if (geom.n <= 0) return DA_OK;
+  const unsigned t = (unsigned)ceil_div(geom.n, 32);
+  hipLaunchKernelGGL(k_finalize_sharded, dim3(t, t), dim3(256), 0, stream, d_g, ld_g, geom, is_nw ? 1 : 0, n_hash, d_out, ld);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
     int kind, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
-    int64_t ld_score, int64_t ntiles, int T, int shard_rank, int shard_world) {
+    int64_t ld_score, int64_t ntiles, int T, int shard_rank, int shard_world, int fold_q, int64_t fold_w) {
   const bool f64_out = kind == DA_OUT_F64;
   __shared__ __attribute__((aligned(16))) Cell tab[CK ? 1 : 24 * 24];
   __shared__ int32_t tabk[CK ? 24 * 24 : 1];
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   int ti, tj;
   bool allow_direct = true, allow_mirror = true;
   int64_t row_shift = -row_begin;  // local output row = global row + row_shift
+  int64_t col_shift = 0;           // local output column = global column + col_shift (direct stores)
   if (symmetric) {
     // row-major over the upper triangle: row t holds T - t tiles
     const double Td = (double)T;
@@ -195,7 +196,11 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     tj = (int)(L % T);
     if (ti >= T || tj < ti) return;
     allow_mirror = false;
-    row_shift = (int64_t)q * K3_TILE - (int64_t)ti * K3_TILE;
+    {  // folded shard layout (ShardGeom): tile rows q and Q-1-q share a stored row
+      const bool front = q <= fold_q - 1 - q;
+      row_shift = (int64_t)(front ? q : fold_q - 1 - q) * K3_TILE - (int64_t)ti * K3_TILE;
+      col_shift = front ? -(int64_t)ti * K3_TILE : fold_w - n;
+    }
   } else {
     // row-block request: tile row rt (inside the block) x every tile column tc.
     // tc >= rt is the upper tile itself (direct store); tc < rt is served by
@@ -352,11 +357,11 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     if (do_mirror) my_res[rr * 64] = (mt << 16) | ln;
     if (do_direct) {
       if (f64_out) {
-        reinterpret_cast<double *>(out_v)[(i + row_shift) * ld + j] = nw_ratio(mt, ln);
+        reinterpret_cast<double *>(out_v)[(i + row_shift) * ld + j + col_shift] = nw_ratio(mt, ln);
       } else if (kind == DA_OUT_PACK32) {
-        reinterpret_cast<uint32_t *>(out_v)[(i + row_shift) * ld + j] = (mt << 16) | ln;
+        reinterpret_cast<uint32_t *>(out_v)[(i + row_shift) * ld + j + col_shift] = (mt << 16) | ln;
       } else {
-        reinterpret_cast<uint16_t *>(out_v)[(i + row_shift) * ld + j] = (uint16_t)((mt << 8) | (ln & 0xffu));
+        reinterpret_cast<uint16_t *>(out_v)[(i + row_shift) * ld + j + col_shift] = (uint16_t)((mt << 8) | (ln & 0xffu));
       }
     }
     if (score_out) {
@@ -629,6 +634,9 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   ScoreTable st;
   for (int e = 0; e < 576; ++e) st.s[e] = tab[e];
   const int T = (int)ceil_div(n, K3_TILE);
+  const ShardGeom sg = shard_geom(n, shard_world > 0 ? shard_world : 1, K3_TILE);
+  const int fold_q = shard_world > 0 ? sg.Q : 0;
+  const int64_t fold_w = sg.W;
   int64_t ntiles;
   if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
   else if (shard_world > 0) ntiles = ceil_div(T, shard_world) * (int64_t)T;
@@ -641,10 +649,10 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
 #define DA_K3(NM)                                                                                   \
   if (ck) hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world);                                  \
+                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w);                   \
   else hipLaunchKernelGGL((k_nw_short<NM, false>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world)
+                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w)
   if (max_len <= 8) DA_K3(8);
   else if (max_len <= 12) DA_K3(12);
   else if (max_len <= 16) DA_K3(16);

@@ -9,8 +9,9 @@ signatures itself; only the result is exchanged:
     every rank expands the gathered blocks to the dense float64 matrix          (HIP kernel)
 
 Tile rows are dealt cyclically so that the triangular work is balanced to within one tile
-row.  The compact payload (2 B/pair instead of 8) is what makes the gather affordable: at
-N = 100k, P = 8 each GPU receives 17.5 GB instead of 70 GB.
+row.  The compact payload (2 B/pair instead of 8) and the folded block layout (only the
+upper triangle travels) are what make the gather affordable: at N = 100k, P = 8 each GPU
+receives 8.8 GB instead of 70 GB.
 
 The orchestration (`Plan`, `all_pairs_sharded`) is independent of where the blocks come from,
 so the world_size-2 gloo tests drive it on CPU with blocks produced by the test oracle; the
@@ -25,25 +26,41 @@ MH_TILE, NW_TILE = 128, 64
 
 
 class Plan:
-    """Which rows a rank owns and where they sit in the gathered buffer."""
+    """Which rows a rank owns and where element (i, j >= i) sits in its block / the gathered buffer.
+
+    Folded layout (csrc/da_common.hpp ShardGeom): rank p owns tile rows t = q*world + p, q = 0..Q-1, and only
+    their part right of the diagonal is valid, so local tile rows q and Q-1-q share one stored tile row of
+    width W = n + world*tile (rounded up to 8): the first left-aligned from its diagonal tile, the second
+    right-aligned.  A block is local_rows x width -- half of a full-width row block."""
 
     def __init__(self, n, rank, world, tile=MH_TILE):
         self.n, self.rank, self.world, self.tile = int(n), int(rank), int(world), int(tile)
-        self.tiles = -(-self.n // self.tile)                       # tile rows of the pair space
-        self.local_tiles = -(-self.tiles // self.world)            # per rank (padded, equal for all ranks)
-        self.local_rows = self.local_tiles * self.tile
+        self.tiles = -(-self.n // self.tile)                       # tile rows of the pair space (T)
+        self.local_tiles = -(-self.tiles // self.world)            # tile rows per rank (Q, padded)
+        self.stored_tiles = (self.local_tiles + 1) // 2            # after folding (Qh)
+        self.local_rows = self.stored_tiles * self.tile
+        self.width = -(-(self.n + self.world * self.tile) // 8) * 8
 
     def owner(self, i):
-        """(rank, local row) of global row i"""
+        """rank owning global row i"""
+        return (i // self.tile) % self.world
+
+    def locate(self, i, j):
+        """(rank, local row, local column) of element (i, j), valid for j >= tile start of i"""
         t = i // self.tile
-        return t % self.world, (t // self.world) * self.tile + i % self.tile
+        q = t // self.world
+        front = q <= self.local_tiles - 1 - q
+        f = q if front else self.local_tiles - 1 - q
+        row = f * self.tile + i % self.tile
+        col = j - t * self.tile if front else self.width - self.n + j
+        return t % self.world, row, col
 
     def gathered_row(self, i):
-        p, r = self.owner(i)
+        p, r, _ = self.locate(i, i)
         return p * self.local_rows + r
 
     def my_rows(self):
-        """global rows owned by this rank, in local order (rows >= n are padding and skipped)"""
+        """global rows owned by this rank (rows >= n are padding and skipped)"""
         out = []
         for q in range(self.local_tiles):
             t = q * self.world + self.rank
@@ -77,8 +94,8 @@ class Workspace:
     """Per-rank HBM buffers for the sharded path (allocated once, reused every step)."""
 
     def __init__(self, plan, device="cuda"):
-        self.local = torch.zeros((plan.local_rows, plan.n), dtype=torch.int16, device=device)
-        self.gathered = torch.empty((plan.world * plan.local_rows, plan.n), dtype=torch.int16, device=device)
+        self.local = torch.zeros((plan.local_rows, plan.width), dtype=torch.int16, device=device)
+        self.gathered = torch.empty((plan.world * plan.local_rows, plan.width), dtype=torch.int16, device=device)
 
 
 MHWorkspace = Workspace

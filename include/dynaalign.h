@@ -176,18 +176,21 @@ int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64
  * Rank p of `world` owns the tile rows p, p+world, p+2*world, ... of the pair
  * space (tile = 128 rows for MH, 64 for NW; cyclic so the upper-triangular work
  * is balanced) and computes only the tiles on or right of the diagonal.  Its
- * result is a compact uint16 block of da_shard_rows() local rows x ld columns
- * (local tile row q = global tile row q*world + p).  One all-gather of those
- * equally sized blocks (RCCL; rank order) followed by da_dev_finalize_shards on
- * every rank reassembles the full float64 matrix.  The reference has no
- * counterpart (it is single-process); the math per pair is unchanged. */
+ * result is a compact uint16 block of da_shard_rows() rows x da_shard_ld()
+ * columns in a FOLDED layout: local tile rows q and Q-1-q share one stored tile
+ * row (the first left-aligned from its diagonal tile, the second right-aligned),
+ * which halves the bytes to exchange.  One all-gather of those equally sized
+ * blocks (RCCL; rank order) followed by da_dev_finalize_shards on every rank
+ * reassembles the full float64 matrix.  The reference has no counterpart (it is
+ * single-process); the math per pair is unchanged. */
 int64_t da_shard_rows(int64_t n, int world, int is_nw);
+int64_t da_shard_ld(int64_t n, int world, int is_nw);
 int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                             int rank, int world, uint16_t *d_local, int64_t ld, void *stream);
 int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len,
                     int matrix_id, int gap_open, int gap_ext, int rank, int world,
                     uint16_t *d_local, int64_t ld, void *stream);
-/* d_gathered: world * da_shard_rows() rows of ld_g uint16 (the all-gather output).
+/* d_gathered: world * da_shard_rows() rows of ld_g >= da_shard_ld() uint16 (the all-gather output).
  * Writes out[i][j] for all i,j < n: MH count/n_hash, NW (v>>8)/(v&255), mirrored. */
 int da_dev_finalize_shards(const uint16_t *d_gathered, int64_t ld_g, int64_t n, int world,
                            int is_nw, int n_hash, double *d_out, int64_t ld_out, void *stream);

@@ -16,30 +16,41 @@ from dynaalign_amd import sharding, synth
 
 
 def finalize_reference(plan, gathered, widen):
-    """numpy statement of k_finalize_sharded: out[i][j] = widen(G[row(min(i,j))][max(i,j)])"""
+    """numpy statement of k_finalize_sharded: out[i][j] = widen(G[entry of (min(i,j), max(i,j))])"""
     n = plan.n
-    rows = np.array([plan.gathered_row(i) for i in range(n)])
-    up = gathered[rows][:, :n]
     iu = np.triu_indices(n)
+    rows = np.empty(len(iu[0]), np.int64)
+    cols = np.empty(len(iu[0]), np.int64)
+    for e, (i, j) in enumerate(zip(*iu)):
+        p, r, c = plan.locate(int(i), int(j))
+        rows[e], cols[e] = p * plan.local_rows + r, c
     out = np.empty((n, n), np.float64)
     with np.errstate(invalid="ignore", divide="ignore"):
-        out[iu] = widen(up[iu])
+        out[iu] = widen(gathered[rows, cols])
     out.T[iu] = out[iu]
     return out
 
 
 @pytest.mark.parametrize("n,world,tile", [(1, 1, 128), (100, 2, 128), (128, 2, 128), (129, 2, 128), (1000, 8, 128),
-                                          (1000, 3, 64), (64, 8, 64), (100000, 8, 128)])
+                                          (1000, 3, 64), (64, 8, 64), (300, 2, 64), (300, 3, 64), (257, 1, 128),
+                                          (100000, 8, 128)])
 def test_plan_partitions_rows_exactly_once(n, world, tile):
     plans = [sharding.Plan(n, r, world, tile) for r in range(world)]
     if n <= 2000:
         owned = sorted(i for p in plans for i in p.my_rows())
         assert owned == list(range(n))
-        seen = {plans[0].gathered_row(i) for i in range(n)}
-        assert len(seen) == n and max(seen) < world * plans[0].local_rows
         for p in plans:
             for i in p.my_rows():
-                assert p.owner(i)[0] == p.rank
+                assert p.owner(i) == p.rank
+    if n <= 300:                                             # no two valid elements share a slot of the folded block
+        seen = set()
+        for i in range(n):
+            for j in range((i // tile) * tile, n):
+                p, r, c = plans[0].locate(i, j)
+                assert 0 <= r < plans[0].local_rows and 0 <= c < plans[0].width
+                key = (p, r, c)
+                assert key not in seen
+                seen.add(key)
     assert len({p.local_rows for p in plans}) == 1          # equal blocks: legal all-gather
     work = [p.upper_pairs() for p in plans]
     if n >= 50 * world * tile:                               # cyclic dealing balances the triangle
@@ -63,25 +74,27 @@ def _rank_main(rank, world, port, n, kind, q):
         tile = sharding.MH_TILE if kind == "mh" else sharding.NW_TILE
         plan = sharding.Plan(n, rank, world, tile)
         rows = plan.my_rows()
-        local = np.full((plan.local_rows, n), 0x7FFF, np.int16)     # poison: must never be read
+        local = np.full((plan.local_rows, plan.width), 0x7FFF, np.int16)     # poison: must never be read
         if kind == "mh":
             sig = O.signatures(seqs, 4, 64, O.seeds(12345, 64))
             for i in rows:
                 t0 = (i // tile) * tile
                 cnt = (sig[i][None, :] == sig[t0:]).sum(1).astype(np.uint16)
-                local[plan.owner(i)[1], t0:] = cnt.view(np.int16)
+                _, r, c0 = plan.locate(i, t0)
+                local[r, c0:c0 + n - t0] = cnt.view(np.int16)
             widen = lambda v: v.view(np.uint16).astype(np.float64) / 64
         else:
             for i in rows:
                 rc, mt, ln, _, _ = O.nw_rows(seqs, i, i + 1)
                 v = ((mt[0] << 8) | ln[0]).astype(np.uint16)
-                local[plan.owner(i)[1], i:] = v[i:].view(np.int16)   # only j >= i is valid for NW
+                _, r, c0 = plan.locate(i, i)
+                local[r, c0:c0 + n - i] = v[i:].view(np.int16)       # only j >= i is valid for NW
 
             def widen(v):
                 u = v.view(np.uint16).astype(np.uint32)
                 return (u >> 8).astype(np.float64) / (u & 255).astype(np.float64)
         local_t = torch.from_numpy(local)
-        gathered = torch.empty((world * plan.local_rows, n), dtype=torch.int16)
+        gathered = torch.empty((world * plan.local_rows, plan.width), dtype=torch.int16)
         out = sharding.all_pairs_sharded(plan, local_t, gathered,
                                          lambda g: finalize_reference(plan, g.numpy(), widen))
         q.put((rank, out))
