@@ -264,7 +264,7 @@ template <bool SYM, bool F64>
 __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const uint32_t *__restrict__ planes, int64_t ld_p, int64_t n, int n_hash, int64_t row_begin,
     int64_t row_end, int tile_stride, int upper_only, int TR, void *__restrict__ out_v, int64_t ld,
-    int64_t ntiles, int64_t per_xcd, int fold_q, int64_t fold_w) {
+    int64_t ntiles, int64_t per_xcd, int fold_q, int64_t fold_w, int band) {
   // Row-block geometry: local tile row q covers global rows row_begin + q*tile_stride*128 + [0,128)
   // (tile_stride = 1: a contiguous block; = world: the cyclic shard of one rank) and is stored at
   // local rows q*128 + [0,128) of `out`.  upper_only skips tiles left of the diagonal.
@@ -272,13 +272,30 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   constexpr int STAGE_UNITS = 2 * K2_TILE * K2_SEGS;
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[K2_NSTAGE * STAGE_UNITS];
 
-  // ---- which tile: blocks b and b+8 share an XCD, so give XCD x the
-  // contiguous id range [x*per_xcd, (x+1)*per_xcd) (speed only).
+  // ---- which tile.  Blocks b and b+8 share an XCD (speed only).
+  //   symmetric: XCD x walks the contiguous id range [x*per_xcd, (x+1)*per_xcd) of the banded
+  //              triangle enumeration (equal work per XCD by construction);
+  //   row block: bands of 8 tile rows are dealt round-robin to the XCDs -- with upper_only the
+  //              valid part of a band shrinks with its row index, and contiguous ranges would
+  //              leave the last XCDs idle (measured: 1.7x slower).
   const int64_t bid = blockIdx.x;
-  const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
-  if (L >= ntiles) return;
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
-  const TileId tid2 = decode_tile(L, TR, T, SYM);
+  TileId tid2;
+  if (SYM) {
+    const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
+    if (L >= ntiles) return;
+    tid2 = decode_tile(L, TR, T, true);
+  } else {
+    const int64_t per_band = (int64_t)band * T;                           // band = tile rows per band (launcher's choice)
+    const int64_t k = bid >> 3;
+    const int r0 = ((int)(bid & 7) + 8 * (int)(k / per_band)) * band;     // first local tile row of the band
+    const int64_t l = k % per_band;
+    const int h = (TR - r0 < band) ? (TR - r0) : band;
+    if (h <= 0) return;
+    tid2.tj = (int)(l / h);
+    tid2.ti = r0 + (int)(l - (int64_t)tid2.tj * h);
+    tid2.valid = tid2.tj < T;
+  }
   if (!tid2.valid) return;
   const int64_t I0 = row_begin + (int64_t)tid2.ti * tile_stride * K2_TILE;  // global row of tile row 0
   const int64_t J0 = (int64_t)tid2.tj * K2_TILE;
@@ -532,12 +549,16 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
   const int TR = (int)ceil_div(ceil_div(row_end - row_begin, K2_TILE), tile_stride);
   const int64_t ntiles = count_tiles(TR, T, symmetric);
   const int64_t per_xcd = ceil_div(ntiles, 8);
-  const int64_t nblocks = per_xcd * 8;
+  // row-block modes: bands of `band` tile rows dealt round-robin to the 8 XCDs; keep >= ~6 bands per
+  // XCD so the deal is even (a band's column operand is re-read from L2 `band` times, so not smaller than needed)
+  int band = K2_BAND;
+  while (band > 1 && ceil_div(TR, band) < 48) band >>= 1;
+  const int64_t nblocks = symmetric ? per_xcd * 8 : 8 * ceil_div(ceil_div(TR, band), 8) * (int64_t)band * T;
   if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
 #define DA_K2(SYM, F64)                                                                              \
   hipLaunchKernelGGL((k_mh_compare<SYM, F64>), grid, block, 0, stream, d_planes, ld_planes, n, n_hash, \
-                     row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w)
+                     row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w, band)
   if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true); else DA_K2(true, false); }
   else           { if (kind == DA_OUT_F64) DA_K2(false, true); else DA_K2(false, false); }
 #undef DA_K2
@@ -546,7 +567,8 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
 }
 
 // Gathered shards -> final matrix.  G holds, for every rank p, its folded local block
-// (ShardGeom); out[i][j] = widen(G[entry of (min(i,j), max(i,j))]).
+// (ShardGeom); out[i][j] = widen(G[entry of (min(i,j), max(i,j))]).  (64- and 128-wide tiles with
+// 16-byte stores and an LDS ratio table were tried and were 10-15 % slower than this simple form.)
 __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__restrict__ G, int64_t ld_g, ShardGeom geom,
                                                           int is_nw, int n_hash, double *__restrict__ out, int64_t ld) {
   __shared__ uint16_t t[32][33];

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-rank phases of the row-sharded path, measured on ONE GPU (the gather itself needs the
+8-GPU node): shard compute for a chosen rank and the finalize kernel at N = 100k."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import dynaalign_amd as da
+from dynaalign_amd import device, sharding, synth
+
+def t_ms(f, reps=3):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+    n_hash = 500
+    res, off = synth.h3n2_like(n, 20)
+    ds = device.DeviceSequences(res, off)
+    sig, planes = device.minhash_signatures(ds, 4, n_hash, da.hash_family_seeds(12345, n_hash))
+    assert int(device.nw_encode(ds).item()) == 0
+    out = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    r = {"n": n}
+    for world in (2, 4, 8):
+        plan = sharding.Plan(n, 0, world, sharding.MH_TILE)
+        work = sharding.Workspace(plan)
+        r["mh_w%d" % world] = {"shard_ms_rank0": t_ms(lambda: sharding.mh_local_block(plan, work, planes, n_hash)),
+                               "finalize_ms": t_ms(lambda: sharding.finalize_shards(plan, work.gathered, False, n_hash, out)),
+                               "block_GB": work.local.numel() * 2 / 1e9, "gathered_GB": work.gathered.numel() * 2 / 1e9}
+        del work
+        nplan = sharding.Plan(n, 0, world, sharding.NW_TILE)
+        nwork = sharding.Workspace(nplan)
+        r["nw_w%d" % world] = {"shard_ms_rank0": t_ms(lambda: sharding.nw_local_block(nplan, nwork, ds), 1),
+                               "finalize_ms": t_ms(lambda: sharding.finalize_shards(nplan, nwork.gathered, True, 0, out))}
+        del nwork
+    print(json.dumps(r))
+
+if __name__ == "__main__":
+    main()
