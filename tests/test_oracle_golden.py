@@ -173,3 +173,13 @@ def test_rows_api_consistent_with_full_matrix():
     with np.errstate(invalid="ignore"):
         R = mt / ln.astype(np.float64)
     assert np.array_equal(np.isnan(R), np.isnan(W)) and np.array_equal(R[~np.isnan(R)], W[~np.isnan(W)])
+
+
+def test_oracle_is_clean_under_asan_ubsan():
+    """CPU sanitizer run of the oracle (GPU sanitizers are not available on the pool)"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", O.ORACLE_DIR, "selftest_asan"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", OMP_NUM_THREADS="2")
+    out = subprocess.run([os.path.join(O.ORACLE_DIR, "selftest_asan")], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "oracle selftest: ok" in out.stdout
