@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "da_common.hpp"
@@ -105,6 +106,62 @@ struct DeviceInput {
     return DA_OK;
   }
 };
+
+
+// Device -> caller-owned pageable host memory (the R matrix).  A plain hipMemcpy of pageable memory
+// staged at ~17 GB/s (measured, profiles/r01_d_host_path.json); this ring of pinned staging buffers
+// keeps the DMA engine streaming while host threads copy finished chunks into the destination.
+// (hipHostRegister of the destination would pin up to 80 GB of R's heap -- not ours to pin.)
+int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
+  constexpr size_t CHUNK = (size_t)64 << 20;
+  constexpr int RING = 4, WORKERS = 4;
+  if (bytes <= CHUNK || getenv("DYNAALIGN_PLAIN_D2H")) {
+    DA_HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return DA_OK;
+  }
+  struct Slot { void *pin = nullptr; hipEvent_t ev = nullptr; };
+  Slot ring[RING];
+  hipStream_t st = nullptr;
+  int rc = DA_OK;
+  auto cleanup = [&]() {
+    for (auto &s : ring) { if (s.pin) (void)hipHostFree(s.pin); if (s.ev) (void)hipEventDestroy(s.ev); }
+    if (st) (void)hipStreamDestroy(st);
+  };
+  auto check = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess && rc == DA_OK) rc = fail(DA_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    return e == hipSuccess;
+  };
+  if (!check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate")) { cleanup(); return rc; }
+  for (auto &s : ring)
+    if (!check(hipHostMalloc(&s.pin, CHUNK, hipHostMallocDefault), "hipHostMalloc") ||
+        !check(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming), "hipEventCreate")) { cleanup(); return rc; }
+  DA_HIP_TRY(hipDeviceSynchronize());  // the producing kernels ran on the null stream
+  const size_t nchunk = (bytes + CHUNK - 1) / CHUNK;
+  auto host_copy = [&](size_t c) {     // pinned slot -> destination, split over a few threads
+    const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
+    const char *src = static_cast<const char *>(ring[c % RING].pin);
+    char *d = static_cast<char *>(dst) + off;
+    std::thread th[WORKERS - 1];
+    const size_t part = (len + WORKERS - 1) / WORKERS;
+    for (int w = 1; w < WORKERS; ++w)
+      th[w - 1] = std::thread([=]() { const size_t b = w * part; if (b < len) memcpy(d + b, src + b, std::min(part, len - b)); });
+    memcpy(d, src, std::min(part, len));
+    for (auto &t : th) t.join();
+  };
+  for (size_t c = 0; c < nchunk + RING - 1 && rc == DA_OK; ++c) {
+    if (c < nchunk) {                  // slot c % RING was drained RING iterations ago
+      const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
+      check(hipMemcpyAsync(ring[c % RING].pin, static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+      check(hipEventRecord(ring[c % RING].ev, st), "hipEventRecord");
+    }
+    if (c >= RING - 1) {
+      const size_t done = c - (RING - 1);
+      if (check(hipEventSynchronize(ring[done % RING].ev), "hipEventSynchronize")) host_copy(done);
+    }
+  }
+  cleanup();
+  return rc;
+}
 
 // How many result rows to keep on the device at once (host-pointer paths).
 int64_t rows_per_block(int64_t n, size_t bytes_per_elem) {
@@ -490,15 +547,15 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   if (whole) {  // everything fits: compare only the upper triangle, store both halves
     rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, kind, dout.p, n, nullptr);
     if (rc != DA_OK) return rc;
-    DA_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * (size_t)n * esz, hipMemcpyDeviceToHost));
+    if ((rc = d2h_pipelined(out, dout.p, (size_t)n * (size_t)n * esz)) != DA_OK) return rc;
     return DA_OK;
   }
   for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
     const int64_t r1 = std::min(row_end, r0 + blk);
     rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr);
     if (rc != DA_OK) return rc;
-    DA_HIP_TRY(hipMemcpy(static_cast<char *>(out) + (size_t)(r0 - row_begin) * (size_t)n * esz, dout.p,
-                         (size_t)(r1 - r0) * (size_t)n * esz, hipMemcpyDeviceToHost));
+    if ((rc = d2h_pipelined(static_cast<char *>(out) + (size_t)(r0 - row_begin) * (size_t)n * esz, dout.p,
+                            (size_t)(r1 - r0) * (size_t)n * esz)) != DA_OK) return rc;
   }
   return DA_OK;
 }
@@ -574,8 +631,8 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
       rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, r0, r1,
                      whole, DA_OUT_F64, dout.p, n, nullptr, 0, nullptr);
       if (rc != DA_OK) return rc;
-      DA_HIP_TRY(hipMemcpy(out_f64 + (size_t)(r0 - row_begin) * (size_t)n, dout.p,
-                           (size_t)(r1 - r0) * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+      if ((rc = d2h_pipelined(out_f64 + (size_t)(r0 - row_begin) * (size_t)n, dout.p,
+                              (size_t)(r1 - r0) * (size_t)n * sizeof(double))) != DA_OK) return rc;
     }
     return DA_OK;
   }
