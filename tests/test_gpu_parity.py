@@ -89,6 +89,24 @@ def test_mh_long_and_ragged_sequences(da):
         assert_same_f64(da.similarityMH(seqs, k, n_hash, seed=99), want)
 
 
+def test_mh_extreme_parameters(da):
+    """large n_hash (count->double table switched off, many plane groups), large k, k > L"""
+    rng = np.random.RandomState(21)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = ["".join(aa[i] for i in rng.randint(0, 20, L)) for L in (40, 41, 300, 64, 33, 200, 40, 1200)]
+    seqs += [seqs[0], seqs[2][:150]]
+    for k, n_hash in ((4, 7000), (33, 64), (64, 31), (301, 16), (2, 6143), (3, 6144)):
+        seeds = da.hash_family_seeds(5, n_hash)
+        sig = O.signatures(seqs, k, n_hash, seeds)
+        assert np.array_equal(da.minhash_signatures(seqs, k, n_hash, seed=5), sig), (k, n_hash)
+        assert np.array_equal(da.mh_counts(seqs, k, n_hash, seed=5), O.mh_counts(sig)), (k, n_hash)
+        rc, want = O.similarity_mh(seqs, k, n_hash, seeds)
+        assert_same_f64(da.similarityMH(seqs, k, n_hash, seed=5), want)
+    with pytest.raises(da.DynaAlignError) as ei:
+        da.similarityMH(seqs, 4, 70000, seed=5)
+    assert ei.value.code == 10
+
+
 def test_mh_row_blocks_and_forced_streaming(da, monkeypatch):
     """row-sharded entry (rect tiles) and the host path's row-block streaming give the same bits"""
     from dynaalign_amd import synth
