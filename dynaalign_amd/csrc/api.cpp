@@ -369,6 +369,31 @@ int da_dev_upper_histogram(const uint16_t *d_compact, int64_t ld, int64_t n, int
                                 static_cast<hipStream_t>(stream));
 }
 
+// The same two steps on ONE RANK'S folded shard block (da_dev_mh_compare_shard output): every unordered
+// pair lives on exactly one rank, so summing the ranks' histograms (an all-reduce of n_hash+1 words) gives
+// the global histogram, and the ranks' edge lists are disjoint -- no N x N exchange at all.
+int da_dev_shard_histogram(const uint16_t *d_local, int64_t ld, int64_t n, int rank, int world, int nbins,
+                           uint64_t *d_hist, void *stream) {
+  if (n <= 0) return DA_OK;
+  if (!d_local || !d_hist || world <= 0 || rank < 0 || rank >= world || nbins <= 0 || nbins > 65536 ||
+      ld < shard_geom(n, world, 128).W)
+    return fail(DA_ERR_BAD_ARG, "bad shard histogram arguments");
+  return launch_upper_histogram(d_local, ld, n, nbins, reinterpret_cast<unsigned long long *>(d_hist),
+                                static_cast<hipStream_t>(stream), rank, world);
+}
+
+int da_dev_shard_extract_edges(const uint16_t *d_local, int64_t ld, int64_t n, int rank, int world,
+                               const uint8_t *d_keep, int nbins, int include_diagonal, int32_t *d_i, int32_t *d_j,
+                               uint16_t *d_v, int64_t capacity, uint64_t *d_count, void *stream) {
+  if (n <= 0) return DA_OK;
+  if (!d_local || !d_keep || !d_i || !d_j || !d_v || !d_count || world <= 0 || rank < 0 || rank >= world || nbins <= 0 ||
+      nbins > 65536 || capacity < 0 || ld < shard_geom(n, world, 128).W)
+    return fail(DA_ERR_BAD_ARG, "bad shard edge-extraction arguments");
+  if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "edge indices are int32");
+  return launch_extract_edges(d_local, ld, n, d_keep, nbins, include_diagonal != 0, d_i, d_j, d_v, capacity,
+                              reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream), rank, world);
+}
+
 int da_dev_extract_edges(const uint16_t *d_compact, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,
                          int include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
                          uint64_t *d_count, void *stream) {

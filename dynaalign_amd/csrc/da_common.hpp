@@ -69,10 +69,10 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
               bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
               int64_t ld_score, hipStream_t stream, int shard_rank = 0, int shard_world = 0);
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
-                           hipStream_t stream);
+                           hipStream_t stream, int rank = 0, int world = 0);
 int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,
                          bool include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
-                         unsigned long long *d_count, hipStream_t stream);
+                         unsigned long long *d_count, hipStream_t stream, int rank = 0, int world = 0);
 int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream);
 int launch_widen(const uint16_t *d_in, double *d_out, int64_t count, bool is_nw, int n_hash,
                  hipStream_t stream);

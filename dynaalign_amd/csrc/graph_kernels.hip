@@ -30,23 +30,43 @@ __device__ __forceinline__ void tri_tile(int64_t L, int T, int &ti, int &tj) {
   tj = (int)(t + (L - start(t)));
 }
 
+// Where the count matrix lives: a dense n x n uint16 matrix (world == 0), or one rank's folded
+// shard block (ShardGeom; rank p holds tile rows q*world + p right of the diagonal).
+struct Layout { ShardGeom g; int rank; int sharded; };
+
+// block id -> upper tile (ti, tj) and the offsets that turn global (i, j) into an element index
+__device__ __forceinline__ bool locate_tile(const Layout &lay, int64_t L, int T, int &ti, int &tj, int64_t &roff, int64_t &coff) {
+  roff = 0; coff = 0;
+  if (!lay.sharded) { tri_tile(L, T, ti, tj); return true; }
+  const int q = (int)(L / T);
+  ti = q * lay.g.world + lay.rank;
+  tj = (int)(L % T);
+  if (ti >= T || tj < ti) return false;
+  const bool front = q <= lay.g.Q - 1 - q;
+  roff = (int64_t)(front ? q : lay.g.Q - 1 - q) * G_TILE - (int64_t)ti * G_TILE;   // local row = i + roff
+  coff = front ? -(int64_t)ti * G_TILE : lay.g.W - lay.g.n;                           // local col = j + coff
+  return true;
+}
+
 // hist[v] += number of pairs i < j with m[i][j] == v
 __global__ __launch_bounds__(G_THREADS) void k_upper_histogram(const uint16_t *__restrict__ m, int64_t ld, int64_t n,
-                                                               int nbins, unsigned long long *__restrict__ hist, int T) {
+                                                               int nbins, unsigned long long *__restrict__ hist, int T,
+                                                               Layout lay) {
   __shared__ unsigned int lh[G_LDS_BINS];
   const bool use_lds = nbins <= G_LDS_BINS;
   if (use_lds)
     for (int b = threadIdx.x; b < nbins; b += G_THREADS) lh[b] = 0;
   __syncthreads();
   int ti, tj;
-  tri_tile(blockIdx.x, T, ti, tj);
+  int64_t roff, coff;
+  const bool live = locate_tile(lay, blockIdx.x, T, ti, tj, roff, coff);   // block-uniform
   const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
   const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;  // 128 columns x 2 rows per pass
   const int64_t j = J0 + cx;
-  for (int r = ry; r < G_TILE; r += 2) {
+  for (int r = ry; live && r < G_TILE; r += 2) {
     const int64_t i = I0 + r;
     if (i < n && j < n && j > i) {
-      const unsigned v = m[i * ld + j];
+      const unsigned v = m[(i + roff) * ld + j + coff];
       if (v < (unsigned)nbins) {
         if (use_lds) atomicAdd(&lh[v], 1u);
         else atomicAdd(&hist[v], 1ull);
@@ -69,11 +89,12 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
                                                              int include_diagonal, int32_t *__restrict__ ei,
                                                              int32_t *__restrict__ ej, uint16_t *__restrict__ ev,
                                                              long long capacity, unsigned long long *__restrict__ count,
-                                                             int T) {
+                                                             int T, Layout lay) {
   __shared__ unsigned int scan[G_THREADS];
   __shared__ unsigned long long tile_base;
   int ti, tj;
-  tri_tile(blockIdx.x, T, ti, tj);
+  int64_t roff, coff;
+  if (!locate_tile(lay, blockIdx.x, T, ti, tj, roff, coff)) return;       // block-uniform
   const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
   const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;   // column cx, rows ry, ry+2, ...
   const int64_t j = J0 + cx;
@@ -81,7 +102,7 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
   for (int q = 0; q < G_TILE / 2; ++q) {
     const int64_t i = I0 + ry + 2 * q;
     if (i < n && j < n && (j > i || (include_diagonal && j == i))) {
-      const unsigned v = m[i * ld + j];
+      const unsigned v = m[(i + roff) * ld + j + coff];
       if (v < (unsigned)nbins && keep[v] != 0) kept |= 1ull << q;
     }
   }
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
       if ((long long)slot < capacity) {
         ei[slot] = (int32_t)i;
         ej[slot] = (int32_t)j;
-        ev[slot] = m[i * ld + j];
+        ev[slot] = m[(i + roff) * ld + j + coff];
       }
       ++slot;
     }
@@ -114,26 +135,37 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
 
 }  // namespace
 
+static Layout make_layout(int64_t n, int rank, int world) {
+  Layout lay;
+  lay.g = shard_geom(n, world > 0 ? world : 1, G_TILE);
+  lay.rank = rank;
+  lay.sharded = world > 0 ? 1 : 0;
+  return lay;
+}
+
+// world == 0: d_m is a dense n x n matrix (ld >= n); world >= 1: d_m is rank's folded shard block (ld >= W)
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
-                           hipStream_t stream) {
+                           hipStream_t stream, int rank, int world) {
   if (n <= 1) return DA_OK;
   const int T = (int)ceil_div(n, G_TILE);
-  const int64_t tiles = (int64_t)T * (T + 1) / 2;
+  const Layout lay = make_layout(n, rank, world);
+  const int64_t tiles = world > 0 ? (int64_t)lay.g.Q * T : (int64_t)T * (T + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
-  hipLaunchKernelGGL(k_upper_histogram, dim3((unsigned)tiles), dim3(G_THREADS), 0, stream, d_m, ld, n, nbins, d_hist, T);
+  hipLaunchKernelGGL(k_upper_histogram, dim3((unsigned)tiles), dim3(G_THREADS), 0, stream, d_m, ld, n, nbins, d_hist, T, lay);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
 
 int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,
                          bool include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
-                         unsigned long long *d_count, hipStream_t stream) {
+                         unsigned long long *d_count, hipStream_t stream, int rank, int world) {
   if (n <= 0) return DA_OK;
   const int T = (int)ceil_div(n, G_TILE);
-  const int64_t tiles = (int64_t)T * (T + 1) / 2;
+  const Layout lay = make_layout(n, rank, world);
+  const int64_t tiles = world > 0 ? (int64_t)lay.g.Q * T : (int64_t)T * (T + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   hipLaunchKernelGGL(k_extract_edges, dim3((unsigned)tiles), dim3(G_THREADS), 0, stream, d_m, ld, n, d_keep, nbins,
-                     include_diagonal ? 1 : 0, d_i, d_j, d_v, (long long)capacity, d_count, T);
+                     include_diagonal ? 1 : 0, d_i, d_j, d_v, (long long)capacity, d_count, T, lay);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

@@ -143,3 +143,63 @@ def nw_sharded_step(plan, work, ds, out, matrix_name="BLOSUM62", gap_open=10, ga
     nw_local_block(plan, work, ds, matrix_name, gap_open, gap_ext)
     return all_pairs_sharded(plan, work.local, work.gathered,
                              lambda g: finalize_shards(plan, g, True, 0, out), group)
+
+
+# ---- threshold + sparsify on the shards: no N x N exchange at all -----------------------------
+# Every unordered pair (i < j) is computed by exactly one rank (the owner of row i's tile row), so
+#   global histogram = sum of the ranks' histograms      (ONE all-reduce of n_hash + 1 words)
+#   global edge list = disjoint union of the ranks' lists (stays distributed)
+# and the quantile threshold clusterbreak needs (reference R/clusterbreak.R:219-221) is exact.
+
+def shard_histogram(plan, local, nbins):
+    hist = torch.zeros(nbins, dtype=torch.int64, device=local.device)
+    _capi.check(_capi.load().da_dev_shard_histogram(local.data_ptr(), local.stride(0), plan.n, plan.rank, plan.world,
+                                                    int(nbins), hist.data_ptr(), _stream()))
+    return hist
+
+
+def shard_extract_edges(plan, local, keep, capacity):
+    import numpy as np
+    dev = local.device
+    keep_t = torch.as_tensor(np.ascontiguousarray(keep, np.uint8)).to(dev)
+    ei = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    ej = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    ev = torch.empty(max(capacity, 1), dtype=torch.int16, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    _capi.check(_capi.load().da_dev_shard_extract_edges(local.data_ptr(), local.stride(0), plan.n, plan.rank, plan.world,
+                                                        keep_t.data_ptr(), keep_t.numel(), 1, ei.data_ptr(), ej.data_ptr(),
+                                                        ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream()))
+    return ei, ej, ev, cnt
+
+
+def edges_from_histograms(plan, local_hist, n_hash, thresh_p, reduce_fn, extract_fn):
+    """Backend-independent part: reduce the histograms, derive threshold + keep mask, extract local edges.
+    local_hist: int64 tensor [n_hash+1] (strict upper triangle of this rank's pairs);
+    reduce_fn(tensor) sums it over ranks in place; extract_fn(keep, capacity) -> (i, j, v, count)."""
+    import numpy as np
+    from .similarity import quantile_type7
+    total = local_hist.clone()
+    reduce_fn(total)
+    values = np.arange(n_hash + 1, dtype=np.float64) / n_hash          # src/minHash.cpp:174
+    thr = quantile_type7(total.cpu().numpy().astype(np.uint64), values, thresh_p)
+    keep = (~(values < thr)) & (np.arange(n_hash + 1) != 0)            # S[S < thr] <- 0; zero weight = no edge
+    mine = local_hist.cpu().numpy()
+    capacity = int(mine[keep].sum()) + len(plan.my_rows())             # + this rank's diagonal entries (1.0)
+    ei, ej, ev, cnt = extract_fn(keep, capacity)
+    return thr, ei, ej, ev, cnt, capacity
+
+
+def mh_edges_sharded(plan, work, planes, n_hash, thresh_p, group=None):
+    """Device pipeline of one rank: shard compare -> local histogram -> all-reduce -> exact type-7 quantile
+    -> this rank's surviving edges (i <= j, 0-based; values are match counts).  Returns
+    (threshold, i, j, count_values, n_local_edges)."""
+    mh_local_block(plan, work, planes, n_hash)
+    hist = shard_histogram(plan, work.local, n_hash + 1)
+
+    def reduce_fn(t):
+        if plan.world > 1:
+            dist.all_reduce(t, group=group)
+
+    thr, ei, ej, ev, cnt, cap = edges_from_histograms(plan, hist, n_hash, thresh_p, reduce_fn,
+                                                      lambda keep, c: shard_extract_edges(plan, work.local, keep, c))
+    return thr, ei, ej, ev, cnt

@@ -221,6 +221,16 @@ int da_dev_extract_edges(const uint16_t *d_compact, int64_t ld, int64_t n, const
                          int nbins, int include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v,
                          int64_t capacity, uint64_t *d_count, void *stream);
 
+/* The same two steps on one rank's folded shard block (da_dev_mh_compare_shard output).  Every
+ * unordered pair lives on exactly one rank: all-reduce the n_hash+1 histogram words, derive the
+ * threshold, and each rank extracts its own (disjoint) edges -- no N x N exchange. */
+int da_dev_shard_histogram(const uint16_t *d_local, int64_t ld, int64_t n, int rank, int world,
+                           int nbins, uint64_t *d_hist, void *stream);
+int da_dev_shard_extract_edges(const uint16_t *d_local, int64_t ld, int64_t n, int rank, int world,
+                               const uint8_t *d_keep, int nbins, int include_diagonal,
+                               int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
+                               uint64_t *d_count, void *stream);
+
 /* name -> id for da_dev_nw; -1 + DA_ERR_BAD_MATRIX message when unknown. */
 int da_matrix_id(const char *matrix_name);
 

@@ -79,3 +79,45 @@ def test_sharded_step_world1_equals_fused_path(da):
     out = torch.empty((n, n), dtype=torch.float64, device="cuda")
     sharding.mh_sharded_step(plan, sharding.Workspace(plan), planes, n_hash, out)
     assert torch.equal(out, fused)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_mh_edges_sharded_virtual_ranks(da, world):
+    """threshold + sparsify on the shards: sum of the ranks' histograms = dense histogram, union of the
+    ranks' edge lists = the dense threshold step (R/clusterbreak.R:219-221) on the oracle matrix"""
+    from dynaalign_amd import device, sharding, synth
+    n, n_hash, p = 900, 500, 0.8
+    res, off = synth.h3n2_like(n, 20)
+    seqs = synth.to_strings(res, off)
+    seeds = da.hash_family_seeds(12345, n_hash)
+    ds = device.DeviceSequences(res, off)
+    sig, planes = device.minhash_signatures(ds, 4, n_hash, seeds)
+    plans = [sharding.Plan(n, r, world, sharding.MH_TILE) for r in range(world)]
+    works = [sharding.Workspace(pl) for pl in plans]
+    hists = []
+    for pl, w in zip(plans, works):
+        w.local.fill_(0x7FFF)
+        sharding.mh_local_block(pl, w, planes, n_hash)
+        hists.append(sharding.shard_histogram(pl, w.local, n_hash + 1))
+    total = torch.stack(hists).sum(0)
+    rc, M = O.similarity_mh(seqs, 4, n_hash, seeds)
+    cnt = np.round(M * n_hash).astype(np.int64)
+    want_hist = np.bincount(cnt[np.triu_indices(n, 1)], minlength=n_hash + 1)
+    assert np.array_equal(total.cpu().numpy(), want_hist)
+    edges = set()
+    thr_seen = set()
+    for pl, w, h in zip(plans, works, hists):
+        thr, ei, ej, ev, c, cap = sharding.edges_from_histograms(
+            pl, h, n_hash, p, lambda t: t.copy_(total),
+            lambda keep, capacity: sharding.shard_extract_edges(pl, w.local, keep, capacity))
+        m = int(c.item())
+        assert m == cap
+        thr_seen.add(thr)
+        for a, b, v in zip(ei[:m].cpu().numpy(), ej[:m].cpu().numpy(), ev[:m].cpu().numpy().view(np.uint16)):
+            key = (int(a), int(b))
+            assert key not in edges and pl.owner(int(a)) == pl.rank
+            edges.add(key)
+            assert v == cnt[a, b]
+    thr_d, i_d, j_d, w_d = da.similarityMH_edges(seqs, 4, n_hash, p, seed=12345)
+    assert thr_seen == {thr_d}
+    assert edges == set(zip(i_d.tolist(), j_d.tolist()))

@@ -122,3 +122,54 @@ def test_sharded_all_gather_reassembles_the_oracle_matrix(world, n, kind):
     assert rc == 0
     for rank, out in results:                                        # every rank ends with the full matrix
         assert np.array_equal(out.view(np.uint64), want.view(np.uint64)), rank
+
+
+def _edges_rank_main(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dynaalign_amd  # noqa: F401  (host-side quantile lives in the library)
+        n_hash, p = 64, 0.8
+        seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+        sig = O.signatures(seqs, 4, n_hash, O.seeds(12345, n_hash))
+        plan = sharding.Plan(n, rank, world, sharding.MH_TILE)
+        cnt = {}
+        for i in plan.my_rows():
+            row = (sig[i][None, :] == sig[i:]).sum(1)
+            for j, c in enumerate(row):
+                cnt[(i, i + j)] = int(c)
+        hist = np.bincount([c for (i, j), c in cnt.items() if j > i], minlength=n_hash + 1).astype(np.int64)
+
+        def extract(keep, capacity):
+            e = sorted((i, j, c) for (i, j), c in cnt.items() if keep[c] or i == j)
+            assert len(e) == capacity
+            return [x[0] for x in e], [x[1] for x in e], [x[2] for x in e], len(e)
+
+        thr, ei, ej, ev, c, cap = sharding.edges_from_histograms(plan, torch.from_numpy(hist), n_hash, p,
+                                                                 lambda t: dist.all_reduce(t), extract)
+        q.put((rank, thr, list(zip(ei, ej, ev))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_edges_all_reduce_matches_dense_threshold(built):
+    """world_size 2 over gloo: one all-reduce of the histogram, then disjoint local edge lists"""
+    from test_threshold_edges import reference_edges
+    world, n = 2, 300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_edges_rank_main, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+    rc, M = O.similarity_mh(seqs, 4, 64, O.seeds(12345, 64))
+    thr_w, iw, jw, ww = reference_edges(M, 0.8)
+    got = sorted(e for _, _, edges in results for e in edges)
+    assert {thr for _, thr, _ in results} == {thr_w}
+    assert [(a, b) for a, b, _ in got] == list(zip(iw.tolist(), jw.tolist()))
+    assert [c / 64 for _, _, c in got] == ww.tolist()
