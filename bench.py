@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--workload", default="h3n2like", choices=["h3n2like", "uniform"])
     ap.add_argument("--no-nw", action="store_true", help="skip the similarityNW measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
+    ap.add_argument("--no-edges", action="store_true", help="skip the threshold + edge-list measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per baseline leg")
     return ap.parse_args()
 
@@ -272,6 +273,34 @@ def main():
         line["nw"] = {"workload": "similarityNW BLOSUM62 go=10 ge=4, same %d 20-mers, dense f64 NxN in HBM" % n,
                       "value": pairs_nw / t_nw, "unit": "pairs/s", "ms": t_nw * 1e3, "gcups": cells / t_nw / 1e9,
                       "hbm_GBs": (n * L + n * n * 8) / t_nw / 1e9, "hbm_frac": (n * L + n * n * 8) / t_nw / 1e9 / HBM_PEAK_GBS}
+
+    # ---- similarityMH + clusterbreak's quantile threshold as a distributed edge list:
+    # shard compare -> histogram -> ONE all-reduce of n_hash+1 words -> exact type-7 quantile -> local edges.
+    # No N x N exchange, so this is the variant of the path whose whole-job time scales with the rank count.
+    if not a.no_edges:
+        eplan = sharding.Plan(n, rank, world, sharding.MH_TILE)
+        ework = sharding.Workspace(eplan, "cuda") if world == 1 else work
+
+        def run_edges():
+            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes)
+            return sharding.mh_edges_sharded(eplan, ework, planes, n_hash, 0.8)
+        run_edges()
+        sync()
+        t0 = time.perf_counter()
+        thr, ei, ej, evv, cnt = run_edges()
+        sync()
+        t_e = time.perf_counter() - t0
+        tot = cnt.clone()
+        if world > 1:
+            t = torch.tensor([t_e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_e = float(t.item())
+            dist.all_reduce(tot)
+        line["edges"] = {"workload": "similarityMH k=4 n_hash=500 + quantile(S[upper.tri(S)], 0.8) threshold -> edge list "
+                                     "(R/clusterbreak.R:219-221), same %d peptides; edges stay distributed over the ranks" % n,
+                         "value": pairs_mh / t_e, "unit": "pairs/s", "ms": t_e * 1e3, "threshold": thr,
+                         "edges_total": int(tot.item()), "edge_list_bytes": int(tot.item()) * 10}
+        del ei, ej, evv
 
     # ---- CPU oracle on this box's host cores (baseline only; rank 0, N = 1)
     if rank == 0 and world == 1 and not a.no_cpu:
