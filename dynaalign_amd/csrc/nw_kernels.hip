@@ -125,10 +125,18 @@ __device__ __forceinline__ double nw_ratio(uint32_t mt, uint32_t ln) {
 // launcher uses it for 0 <= gapOpen, gapExt and gapOpen + 64*gapExt <= 7000 with the
 // "minus infinity" sentinel at -24000 (any value below every reachable score gives the
 // same decisions as the reference's INT_MIN/2; the int32 kernel covers everything else).
-constexpr int CK_S = 13, CK_S2 = 15;
-constexpr int32_t CK_LOW = (1 << CK_S2) - 1;   // priority + payload bits
-constexpr int32_t CK_PRI = 3 << CK_S;
-constexpr int32_t CK_NEG = -24000;
+// Bit budget per length class (the launcher checks the penalty limit):
+//   <= 32 residues: length 7 bits, matches 6 bits -> score 17 bits, sentinel -24000, gapOpen + 64*gapExt <= 7000
+//   <= 64 residues: length 8 bits, matches 7 bits -> score 15 bits, sentinel  -6000, gapOpen + 128*gapExt <= 2500
+template <int NMAX> struct CKBits {
+  static constexpr int LB = NMAX <= 32 ? 7 : 8;              // bits of the alignment length
+  static constexpr int S = NMAX <= 32 ? 13 : 15;             // payload bits (matches << LB | length)
+  static constexpr int S2 = S + 2;                           // score starts here (2 priority bits)
+  static constexpr int32_t LOW = (1 << S2) - 1;              // priority + payload bits
+  static constexpr int32_t PRI = 3 << S;
+  static constexpr int32_t NEG = NMAX <= 32 ? -24000 : -6000;
+  static constexpr int GAP_LIMIT = NMAX <= 32 ? 7000 : 2500; // gapOpen + 2*NMAX*gapExt must stay below
+};
 
 //   VM[c] : combined M[r-1][c] (priority cleared)         XP[c] : Ix[r-1][c]*2^15 | payload of cell (r-1,c)
 template <int NMAX, bool FIRST>
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   for (int e = threadIdx.x; e < 576; e += K3_THREADS) {
     const int a = e / 24, b = e - a * 24;
     if (CK) {
-      tabk[e] = ((int32_t)table.s[e] << CK_S2) + (2 << CK_S) + 1 + ((a == b) ? 128 : 0);
+      tabk[e] = ((int32_t)table.s[e] << CKBits<NMAX>::S2) + (2 << CKBits<NMAX>::S) + 1 + ((a == b) ? (1 << CKBits<NMAX>::LB) : 0);
     } else {
       tab[e].s_goe = (int32_t)table.s[e] + goe;
       tab[e].inc = 1u + ((a == b) ? 0x10000u : 0u);  // equal index <=> equal residue byte (:291-293)
@@ -274,6 +282,8 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     uint32_t mt, ln;
     int32_t sc;
     if constexpr (CK) {
+      constexpr int CK_S = CKBits<NMAX>::S, CK_S2 = CKBits<NMAX>::S2, CK_LB = CKBits<NMAX>::LB;
+      constexpr int32_t CK_LOW = CKBits<NMAX>::LOW, CK_PRI = CKBits<NMAX>::PRI, CK_NEG = CKBits<NMAX>::NEG;
       // row 0 (reference :222-235) in combined form: only its max(M,Ix,Iy) feeds row 1's diagonal
       int32_t VM[NMAX], XP[NMAX];
 #pragma unroll
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
       } else {
 #pragma unroll
         for (int c = 0; c < NMAX; ++c)
-          if (nj == c + 1) { mt = ((uint32_t)VM[c] >> 7) & 63u; ln = (uint32_t)VM[c] & 127u; sc = VM[c] >> CK_S2; }
+          if (nj == c + 1) { mt = ((uint32_t)VM[c] >> CK_LB) & ((1u << (CK_S - CK_LB)) - 1u); ln = (uint32_t)VM[c] & ((1u << CK_LB) - 1u); sc = VM[c] >> CK_S2; }
       }
     } else {
     // row 0 of the DP (reference :222-235)
@@ -604,8 +614,14 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
                 (long long)max_len);
   if (kind == DA_OUT_COMPACT && max_len > 127)
     return fail(DA_ERR_UNSUPPORTED, "uint16 NW output needs alignment length <= 255 (use the float64 or 32-bit packed kind)");
-  if (max_len > 32) {  // wavefront-per-pair anti-diagonal kernel
-    if (shard_world > 0) return fail(DA_ERR_UNSUPPORTED, "row-sharded NW is built for sequences up to 32 residues");
+  // fast path: scores fit the score field of the combined key (see nw_row_ck / CKBits)
+  const int64_t gap_span = (int64_t)gap_open + 2 * (max_len <= 32 ? 32 : 64) * (int64_t)gap_ext;
+  const bool ck = gap_open >= 0 && gap_ext >= 0 && gap_span <= (max_len <= 32 ? 7000 : 2500) && !getenv("DYNAALIGN_NW_INT32");
+  // <= 32 residues: register-resident lane-per-pair kernel (either cell update);
+  // 33..64: the same kernel with the combined key only (the int32 form would need > 256 VGPRs);
+  // otherwise the wavefront-per-pair anti-diagonal kernel
+  if (max_len > 64 || (max_len > 32 && !ck)) {
+    if (shard_world > 0) return fail(DA_ERR_UNSUPPORTED, "row-sharded NW is built for sequences up to 64 residues (default-range gap penalties)");
     ScoreTable st4;
     for (int e = 0; e < 576; ++e) st4.s[e] = tab[e];
     const int T8 = (int)ceil_div(n, K4_TILE);
@@ -643,9 +659,6 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
   if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)ntiles), block(K3_THREADS);
-  // fast path: scores fit the 17-bit field of the combined key (see nw_row_ck)
-  const bool ck = gap_open >= 0 && gap_ext >= 0 && (int64_t)gap_open + 64 * (int64_t)gap_ext <= 7000 &&
-                  !getenv("DYNAALIGN_NW_INT32");
 #define DA_K3(NM)                                                                                   \
   if (ck) hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
@@ -658,7 +671,15 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   else if (max_len <= 16) DA_K3(16);
   else if (max_len <= 20) DA_K3(20);
   else if (max_len <= 24) DA_K3(24);
-  else DA_K3(32);
+  else if (max_len <= 32) DA_K3(32);
+  else {
+#define DA_K3CK(NM)                                                                                    \
+  hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
+                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
+                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w)
+    if (max_len <= 48) DA_K3CK(48); else DA_K3CK(64);
+#undef DA_K3CK
+  }
 #undef DA_K3
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;

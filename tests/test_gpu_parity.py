@@ -286,6 +286,22 @@ def test_nw_long_other_matrices_and_gaps(da):
         assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc), (name, go, ge)
 
 
+@pytest.mark.parametrize("lengths", [(33, 48, 40, 20, 0, 47, 48, 35), (64, 49, 60, 5, 64, 33)])
+def test_nw_mid_length_lane_per_pair(da, lengths):
+    """33..64 residues: lane-per-pair kernel with the 15-bit-score combined key; penalties outside its
+    range fall back to the wavefront-per-pair kernel -- both must agree with the oracle"""
+    rng = np.random.RandomState(len(lengths))
+    seqs = _rand_seqs(rng, lengths) + _rand_seqs(rng, lengths[:3], "AGW")
+    seqs.append(seqs[0][:-2] + "WW")
+    for name, go, ge in (("BLOSUM62", 10, 4), ("BLOSUM100", 0, 0), ("BLOSUM45", 2400, 0), ("BLOSUM80", 12, 19),
+                         ("BLOSUM62", 10, 20), ("BLOSUM50", 3000, 1)):
+        rc, omt, oln, osc, _ = O.nw_rows(seqs, 0, None, name, go, ge)
+        mt, ln, sc = da.nw_pairs(seqs, name, go, ge)
+        assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc), (name, go, ge)
+    rc, want, _ = O.similarity_nw(seqs)
+    assert_same_f64(da.similarityNW(seqs), want)
+
+
 def test_nw_too_long_sequences_fail_loudly(da):
     with pytest.raises(da.DynaAlignError) as ei:
         da.similarityNW(["A" * 1025, "C" * 10])
