@@ -63,15 +63,24 @@ __global__ __launch_bounds__(G_THREADS) void k_upper_histogram(const uint16_t *_
   const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
   const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;  // 128 columns x 2 rows per pass
   const int64_t j = J0 + cx;
+  // The overwhelmingly common value is 0 (unrelated peptides share no k-mer): counted in a register,
+  // not with 64 lanes hammering one LDS word (same-address atomics serialise).
+  unsigned zeros = 0;
   for (int r = ry; live && r < G_TILE; r += 2) {
     const int64_t i = I0 + r;
     if (i < n && j < n && j > i) {
       const unsigned v = m[(i + roff) * ld + j + coff];
-      if (v < (unsigned)nbins) {
+      if (v == 0) ++zeros;
+      else if (v < (unsigned)nbins) {
         if (use_lds) atomicAdd(&lh[v], 1u);
         else atomicAdd(&hist[v], 1ull);
       }
     }
+  }
+  for (int o = 32; o > 0; o >>= 1) zeros += __shfl_down(zeros, o);          // wave sum
+  if ((threadIdx.x & 63) == 0 && zeros) {
+    if (use_lds) atomicAdd(&lh[0], zeros);
+    else atomicAdd(&hist[0], (unsigned long long)zeros);
   }
   __syncthreads();
   if (use_lds)
