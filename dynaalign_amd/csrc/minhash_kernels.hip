@@ -332,11 +332,26 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     // row operand (a) from the plain copy, column operand (b) from the pair-swapped copy
     src[q] = planes + g * ld_p + ((s < 128) ? 0 : (ld_p >> 1)) + seg * 4;
   }
+  // The DMA is issued from inline asm on purpose: with the builtin, hipcc must assume the LDS write may
+  // alias the ring slots being read and puts s_waitcnt vmcnt(0) in front of the first ds_read of every
+  // segment, which drains the "asynchronous" copy at every stage (seen in the ISA).  Hidden in asm the
+  // copies stay in flight; the counted waits below (wait_stage) are then OUR responsibility:
+  // each wave issues exactly 4 VMEM operations per stage and nothing else touches vmcnt in the loop.
+  const uint32_t lds_wave_base =
+      __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)(lds_ab + wave * 4 * 64));
   auto issue = [&](int stage) {  // stage s holds planes [16 s, 16 s + 16)
-    uint4 *base = lds_ab + (stage % K2_NSTAGE) * STAGE_UNITS + wave * 4 * 64;
+    const uint32_t base = lds_wave_base + (uint32_t)(stage % K2_NSTAGE) * (uint32_t)(STAGE_UNITS * sizeof(uint4));
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(src[q] + stage * K2_SP), (lds_void_t *)(base + q * 64), 16, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t *g = src[q] + stage * K2_SP;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(g), "s"(base + (uint32_t)(q * 64 * sizeof(uint4))) : "memory", "m0");
+    }
+  };
+  // before the barrier that opens stage s: its 4 copies must have landed; the 4 of stage s+1 may still fly
+  auto wait_stage = [&](bool younger_in_flight) {
+    if (younger_in_flight) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   uint32_t mis[8][4];  // mismatch counters, two 16-bit counters per register (columns 2j, 2j+1)
@@ -361,12 +376,15 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     for (int seg = 0; seg < K2_SEGS; ++seg) {  // 4 planes per 16-byte segment
       const uint4 *Sa = S + base_a + (seg ^ xa);
       const uint4 *Sb = S + base_b + (seg ^ xb);
+      // first column operand first, then the 8 row operands: LDS returns in order, so the first
+      // v_bitop3 can start after two reads instead of nine (the compiler emits counted lgkmcnt waits)
+      uint4 b = Sb[0];
       uint4 a[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) a[r] = Sa[r * 16 * K2_SEGS];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const uint4 b = Sb[c * 16 * K2_SEGS];
+        const uint4 bn = (c + 1 < 8) ? Sb[(c + 1) * 16 * K2_SEGS] : b;   // next column's operand in flight
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           // b holds planes (1,0,3,2): plane p sits in registers of opposite index parity in
@@ -376,6 +394,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
           v = or_xor(v, a[r].z, b.w);
           d[r][c] = or_xor(v, a[r].w, b.z);
         }
+        b = bn;
       }
     }
   };
@@ -385,12 +404,13 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   issue(0);
   issue(1);
   for (int g = 0; g < ngroup; ++g) {
-    // The barrier's fence drains this wave's DMA (vmcnt(0)): stages 2g and 2g+1 have
-    // landed for every wave, and nobody still reads the buffer stage 2g+2 goes to
-    // (it was consumed as stage 2g-1, before this barrier).
+    // wait_stage: this wave's copies for the stage have landed; the barrier: so have everyone's, and
+    // nobody still reads the ring slot the next issue() overwrites (it was consumed two stages ago).
+    wait_stage(true);                       // stage 2g+1 was issued after stage 2g
     __syncthreads();
     if (2 * g + 2 < nstage) issue(2 * g + 2);
     compute(2 * g);
+    wait_stage(2 * g + 2 < nstage);         // stage 2g+2 (if any) is younger than stage 2g+1
     __syncthreads();
     if (2 * g + 3 < nstage) issue(2 * g + 3);
     compute(2 * g + 1);
