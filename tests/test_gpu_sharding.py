@@ -121,3 +121,20 @@ def test_mh_edges_sharded_virtual_ranks(da, world):
     thr_d, i_d, j_d, w_d = da.similarityMH_edges(seqs, 4, n_hash, p, seed=12345)
     assert thr_seen == {thr_d}
     assert edges == set(zip(i_d.tolist(), j_d.tolist()))
+
+
+def test_symmetrize_and_widen_helpers(da):
+    """da_dev_symmetrize (lower <- upper) and da_dev_widen on small matrices of both element kinds"""
+    from dynaalign_amd import device, _capi
+    rng = np.random.RandomState(4)
+    for n in (1, 31, 32, 33, 200):
+        a = rng.randint(0, 500, (n, n)).astype(np.int16)
+        t = torch.from_numpy(a.copy()).cuda()
+        device.symmetrize(t, n, _capi.DA_OUT_COMPACT)
+        want = np.triu(a) + np.triu(a, 1).T
+        assert np.array_equal(t.cpu().numpy(), want)
+        f = torch.from_numpy(rng.rand(n, n)).cuda()
+        g = f.clone()
+        device.symmetrize(g, n, _capi.DA_OUT_F64)
+        fw = f.cpu().numpy()
+        assert np.array_equal(g.cpu().numpy(), np.triu(fw) + np.triu(fw, 1).T)
