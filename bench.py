@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-nw", action="store_true", help="skip the similarityNW measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-edges", action="store_true", help="skip the threshold + edge-list measurement")
+    ap.add_argument("--plane-bits", type=int, default=16, choices=[16, 32],
+                    help="16: compare the signatures' exact dictionary codes (default); 32: raw signature bits")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per baseline leg")
     return ap.parse_args()
 
@@ -158,6 +160,24 @@ def main():
     d_seeds = torch.from_numpy(seeds.view(np.int32).copy()).cuda()
     sig = torch.empty((n, device.sig_ld(n_hash)), dtype=torch.int32, device="cuda")
     planes = torch.empty((n, device.planes_ld(n_hash)), dtype=torch.int32, device="cuda")
+    pwork = torch.empty(device.planes_workspace_bytes(n, n_hash), dtype=torch.uint8, device="cuda")
+    raw = a.plane_bits == 32
+    state = {"bits": 32}
+
+    def signatures_and_planes(e=None):
+        """K1 (signatures) + K1b (dictionary codes -> 16 bit planes per 32 hash functions); --plane-bits 32
+        keeps the raw 32-plane operand K1 writes itself."""
+        if raw:
+            pl = device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes, raw_planes=True)[1]
+            if e is not None:
+                e.record()
+            return pl
+        device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, want_planes=False)
+        if e is not None:
+            e.record()
+        pl = device.mh_planes(sig, n, n_hash, planes, pwork)
+        state["bits"] = pl.bits
+        return pl
     out = torch.empty((n, n), dtype=torch.float64, device="cuda")
 
     pairs_mh = n * (n - 1) // 2            # unordered pairs, diagonal excluded (src/minHash.cpp:164)
@@ -167,31 +187,31 @@ def main():
 
     if world == 1:
         def step():
-            e = [ev() for _ in range(3)]
+            e = [ev() for _ in range(4)]
             e[0].record()
-            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes)
-            e[1].record()
-            device.mh_compare(planes, n, n_hash, 0, n, True, _capi.DA_OUT_F64, out=out)
+            pl = signatures_and_planes(e[1])
             e[2].record()
+            device.mh_compare(pl, n, n_hash, 0, n, True, _capi.DA_OUT_F64, out=out)
+            e[3].record()
             return e
-        phase_names = ["k1_signatures", "k2_compare"]
+        phase_names = ["k1_signatures", "k1b_codes_to_planes", "k2_compare"]
     else:
         plan = sharding.Plan(n, rank, world, sharding.MH_TILE)
         work = sharding.Workspace(plan, "cuda")
 
         def step():
-            e = [ev() for _ in range(5)]
+            e = [ev() for _ in range(6)]
             e[0].record()
-            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes)  # every rank: all signatures (2 MB in)
-            e[1].record()
-            sharding.mh_local_block(plan, work, planes, n_hash)
+            pl = signatures_and_planes(e[1])                      # every rank: all signatures (2 MB in)
             e[2].record()
-            sharding.all_pairs_sharded(plan, work.local, work.gathered, lambda gathered: gathered)
+            sharding.mh_local_block(plan, work, pl, n_hash)
             e[3].record()
-            sharding.finalize_shards(plan, work.gathered, False, n_hash, out)
+            sharding.all_pairs_sharded(plan, work.local, work.gathered, lambda gathered: gathered)
             e[4].record()
+            sharding.finalize_shards(plan, work.gathered, False, n_hash, out)
+            e[5].record()
             return e
-        phase_names = ["k1_signatures", "k2_compare_shard", "all_gather", "finalize"]
+        phase_names = ["k1_signatures", "k1b_codes_to_planes", "k2_compare_shard", "all_gather", "finalize"]
 
     def sync():
         if world > 1:
@@ -216,20 +236,22 @@ def main():
     # ---- roofline of the dominant kernel (K2 compare); duration from HIP events on the launch stream
     k2_key = "k2_compare" if world == 1 else "k2_compare_shard"
     k2 = phases[k2_key] * 1e-3
+    plane_bits = state["bits"]
+    planes_row_bytes = 2 * 16 * plane_bits * 4        # two copies x 16 groups x planes x 4 B
     T = (n + 127) // 128
     if world == 1:
-        bytes_k2 = n * 1024 * 4 + n * n * 8           # read the bit planes once + write the f64 N x N
+        bytes_k2 = n * planes_row_bytes + n * n * 8   # read the bit planes once + write the f64 N x N
         tiles = T * (T + 1) // 2
     else:
         tiles = sum(T - t for t in range(rank, T, world))
-        bytes_k2 = n * 1024 * 4 + tiles * 128 * 128 * 2   # this rank's uint16 tiles
-    lane_ops = tiles * 128 * 128 * 512                # one v_bitop3 per pair and bit plane (16 groups x 32 planes)
-    traffic = pmc_traffic("k_mh_compare<true, true>") if world == 1 else None
+        bytes_k2 = n * planes_row_bytes + tiles * 128 * 128 * 2   # this rank's uint16 tiles
+    lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 16|32 planes)
+    traffic = pmc_traffic("k_mh_compare<true, true, %d>" % plane_bits) if world == 1 else None
     roof = {"kernel": "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic["bytes"] if traffic and traffic.get("n") == n else None,
             "traffic_source": traffic["source"] if traffic and traffic.get("n") == n else None,
-            "avg_launch_ms": k2 * 1e3, "algorithmic_bytes_per_launch": bytes_k2,
+            "avg_launch_ms": k2 * 1e3, "algorithmic_bytes_per_launch": bytes_k2, "plane_bits": plane_bits,
             "valu": {"note": "the unit that actually binds: bit-sliced compare = 1 v_bitop3 per pair per bit plane; "
                              "peak = isolated v_bitop3 issue rate measured on this chip",
                      "lane_ops_per_launch": lane_ops, "achieved_lane_ops_per_s": lane_ops / k2,
@@ -282,8 +304,7 @@ def main():
         ework = sharding.Workspace(eplan, "cuda") if world == 1 else work
 
         def run_edges():
-            device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes)
-            return sharding.mh_edges_sharded(eplan, ework, planes, n_hash, 0.8)
+            return sharding.mh_edges_sharded(eplan, ework, signatures_and_planes(), n_hash, 0.8)
         run_edges()
         sync()
         t0 = time.perf_counter()

@@ -18,7 +18,7 @@ DA_ERR_BAD_RESIDUE_SEQ1, DA_ERR_BAD_RESIDUE_SEQ2, DA_ERR_NOMEM, DA_ERR_NO_DEVICE
 DA_ERR_HIP, DA_ERR_UNSUPPORTED, DA_ERR_BAD_ARG = 9, 10, 11
 DA_OUT_F64, DA_OUT_COMPACT, DA_OUT_PACK32 = 0, 1, 2
 
-_vp, _i64, _i32, _u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32
+_vp, _i64, _i32, _u32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_size_t
 
 # name -> (restype, argtypes).  Must list every symbol include/dynaalign.h declares
 # (tests/test_abi.py checks the two against each other).
@@ -37,7 +37,9 @@ SIGNATURES = {
     "da_sig_ld": (_i64, [_i32]),
     "da_planes_ld": (_i64, [_i32]),
     "da_dev_minhash_signatures": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
-    "da_dev_mh_compare": (_i32, [_vp, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "da_mh_planes_workspace_bytes": (_sz, [_i64, _i32]),
+    "da_dev_mh_planes": (_i32, [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _i64, _vp, _vp]),
+    "da_dev_mh_compare": (_i32, [_vp, _i64, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "da_similarity_mh_edges": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, C.c_double, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -49,7 +51,7 @@ SIGNATURES = {
     "da_matrix_id": (_i32, [C.c_char_p]),
     "da_shard_rows": (_i64, [_i64, _i32, _i32]),
     "da_shard_ld": (_i64, [_i64, _i32, _i32]),
-    "da_dev_mh_compare_shard": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "da_dev_mh_compare_shard": (_i32, [_vp, _i64, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_shard": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_finalize_shards": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_symmetrize": (_i32, [_vp, _i64, _i64, _i32, _vp]),

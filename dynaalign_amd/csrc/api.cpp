@@ -264,7 +264,45 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
                                    ld_planes, static_cast<hipStream_t>(stream));
 }
 
-int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
+// signatures -> compare operand: dictionary codes (16 planes / group) when n allows, raw values otherwise
+static int forced_plane_bits() {
+  const char *e = getenv("DYNAALIGN_PLANE_BITS");
+  return (e && atoi(e) == 32) ? 32 : 0;
+}
+static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work, size_t work_bytes,
+                        uint32_t *d_planes, int64_t ld_planes, int *bits_out, hipStream_t stream) {
+  int rc;
+  if (n <= DA_DICT_MAX_N && forced_plane_bits() != 32) {
+    if (!d_work || work_bytes < mh_planes_workspace_bytes(n, n_hash))
+      return fail(DA_ERR_BAD_ARG, "workspace smaller than da_mh_planes_workspace_bytes(n, n_hash)");
+    int *d_status = nullptr;
+    if ((rc = launch_mh_dictionary_planes(d_sig, ld_sig, n, n_hash, d_work, d_planes, ld_planes, &d_status, stream)) != DA_OK)
+      return rc;
+    int status = 0;
+    DA_HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+    if (status == 0) { *bits_out = 16; return DA_OK; }
+  }
+  *bits_out = 32;
+  return launch_sig_to_planes(d_sig, ld_sig, n, n_hash, d_planes, ld_planes, stream);
+}
+
+size_t da_mh_planes_workspace_bytes(int64_t n, int n_hash) { return mh_planes_workspace_bytes(n, n_hash); }
+
+int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work, size_t work_bytes,
+                     uint32_t *d_planes, int64_t ld_planes, int *plane_bits_out, void *stream) {
+  if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
+  if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
+  if (!d_sig || !d_planes || !plane_bits_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (ld_sig < n_hash) return fail(DA_ERR_BAD_ARG, "ld_sig (%lld) < n_hash (%d)", (long long)ld_sig, n_hash);
+  if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
+    return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
+  if (reinterpret_cast<uintptr_t>(d_work) & 255) return fail(DA_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+  return build_planes(d_sig, ld_sig, n, n_hash, d_work, work_bytes, d_planes, ld_planes, plane_bits_out,
+                      static_cast<hipStream_t>(stream));
+}
+
+int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, int symmetric, int kind, void *d_out,
                       int64_t ld, void *stream) {
   if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
@@ -279,8 +317,9 @@ int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
     return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
   if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
     return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
+  if (plane_bits != 16 && plane_bits != 32) return fail(DA_ERR_BAD_ARG, "plane_bits must be 16 or 32 (got %d)", plane_bits);
   return launch_mh_compare(d_planes, ld_planes, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
-                           static_cast<hipStream_t>(stream));
+                           static_cast<hipStream_t>(stream), plane_bits);
 }
 
 int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues, uint8_t *d_codes,
@@ -325,7 +364,7 @@ int64_t da_shard_ld(int64_t n, int world, int is_nw) {
   return shard_geom(n, world, is_nw ? 64 : 128).W;
 }
 
-int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash, int rank,
+int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash, int rank,
                             int world, uint16_t *d_local, int64_t ld, void *stream) {
   if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
   if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
@@ -335,9 +374,10 @@ int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int64_t
   if (ld < sg.W) return fail(DA_ERR_BAD_ARG, "ld (%lld) < da_shard_ld (%lld)", (long long)ld, (long long)sg.W);
   if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
     return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
+  if (plane_bits != 16 && plane_bits != 32) return fail(DA_ERR_BAD_ARG, "plane_bits must be 16 or 32 (got %d)", plane_bits);
   if ((int64_t)rank * 128 >= n) return DA_OK;  // this rank owns no rows
   return launch_mh_compare(d_planes, ld_planes, n, n_hash, (int64_t)rank * 128, n, false, DA_OUT_COMPACT, d_local, ld,
-                           static_cast<hipStream_t>(stream), world, true, sg.Q, sg.W);
+                           static_cast<hipStream_t>(stream), plane_bits, world, true, sg.Q, sg.W);
 }
 
 int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len, int matrix_id,
@@ -458,8 +498,17 @@ int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int6
   if ((rc = hist.alloc((size_t)nbins * 8)) != DA_OK) return rc;
   DA_HIP_TRY(hipMemset(hist.p, 0, (size_t)nbins * 8));
   if ((rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash, in.seeds.as<uint32_t>(),
-                                      sig.as<uint32_t>(), lds, planes.as<uint32_t>(), ldp, nullptr)) != DA_OK) return rc;
-  if ((rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, DA_OUT_COMPACT, cnt.p, n, nullptr)) != DA_OK)
+                                      sig.as<uint32_t>(), lds, nullptr, 0, nullptr)) != DA_OK) return rc;
+  int bits = 32;
+  {
+    DevBuf work;
+    const size_t wb = mh_planes_workspace_bytes(n, n_hash);
+    if ((rc = work.alloc(wb)) != DA_OK) return rc;
+    if ((rc = build_planes(sig.as<uint32_t>(), lds, n, n_hash, work.p, wb, planes.as<uint32_t>(), ldp, &bits, nullptr)) != DA_OK)
+      return rc;
+    DA_HIP_TRY(hipStreamSynchronize(nullptr));   // the workspace is released here
+  }
+  if ((rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, DA_OUT_COMPACT, cnt.p, n, nullptr, bits)) != DA_OK)
     return rc;
   if ((rc = launch_upper_histogram(cnt.as<uint16_t>(), n, n, nbins, hist.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
   std::vector<uint64_t> h(nbins);
@@ -560,9 +609,17 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   const int64_t ldp = 2 * lds;
   if ((rc = planes.alloc((size_t)n * ldp * sizeof(uint32_t))) != DA_OK) return rc;
   rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
-                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, planes.as<uint32_t>(), ldp,
-                                 nullptr);
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, nullptr, 0, nullptr);
   if (rc != DA_OK) return rc;
+  int bits = 32;
+  {
+    DevBuf work;
+    const size_t wb = mh_planes_workspace_bytes(n, n_hash);
+    if ((rc = work.alloc(wb)) != DA_OK) return rc;
+    if ((rc = build_planes(sig.as<uint32_t>(), lds, n, n_hash, work.p, wb, planes.as<uint32_t>(), ldp, &bits, nullptr)) != DA_OK)
+      return rc;
+    DA_HIP_TRY(hipStreamSynchronize(nullptr));   // the workspace is released here
+  }
   const size_t esz = kind == DA_OUT_F64 ? sizeof(double) : sizeof(uint16_t);
   const int64_t rows_total = row_end - row_begin;
   const int64_t blk = rows_per_block(n, esz);
@@ -570,14 +627,14 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   DevBuf dout;
   if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * esz)) != DA_OK) return rc;
   if (whole) {  // everything fits: compare only the upper triangle, store both halves
-    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, kind, dout.p, n, nullptr);
+    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, kind, dout.p, n, nullptr, bits);
     if (rc != DA_OK) return rc;
     if ((rc = d2h_pipelined(out, dout.p, (size_t)n * (size_t)n * esz)) != DA_OK) return rc;
     return DA_OK;
   }
   for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
     const int64_t r1 = std::min(row_end, r0 + blk);
-    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr);
+    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr, bits);
     if (rc != DA_OK) return rc;
     if ((rc = d2h_pipelined(static_cast<char *>(out) + (size_t)(r0 - row_begin) * (size_t)n * esz, dout.p,
                             (size_t)(r1 - r0) * (size_t)n * esz)) != DA_OK) return rc;

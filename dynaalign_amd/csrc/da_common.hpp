@@ -58,8 +58,17 @@ int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_
                               hipStream_t stream);
 int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
-                      void *d_out, int64_t ld, hipStream_t stream, int tile_stride = 1,
+                      void *d_out, int64_t ld, hipStream_t stream, int plane_bits = 32, int tile_stride = 1,
                       bool upper_only = false, int fold_q = 0, int64_t fold_w = 0);
+// dict_kernels.hip: signatures -> compare operand.  Dictionary codes (16 planes per group) are exact
+// for n <= DA_DICT_MAX_N; *d_status_out points into the workspace (0 = ok) and is valid once the
+// stream has drained.
+constexpr int64_t DA_DICT_MAX_N = 131068;
+size_t mh_planes_workspace_bytes(int64_t n, int n_hash);
+int launch_mh_dictionary_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work,
+                                uint32_t *d_planes, int64_t ld_planes, int **d_status_out, hipStream_t stream);
+int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, uint32_t *d_planes,
+                         int64_t ld_planes, hipStream_t stream);
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
                             double *d_out, int64_t ld, hipStream_t stream);
 int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,

@@ -1,0 +1,278 @@
+// dict_kernels.hip -- exact 16-bit re-coding of the MinHash signatures before the compare.
+//
+// The compare (reference src/minHash.cpp:168-173) only asks whether sig[i][h] == sig[j][h].
+// Any per-column injective re-coding of the values keeps every answer, and a value that occurs
+// in ONE sequence of column h can never match anything.  So per hash function h:
+//     values seen >= 2 times  ->  dense ids 0 .. D-1               (D <= n/2)
+//     values seen once        ->  0xFFFE on the row side, 0xFFFF on the column side
+// (row and column operands of the compare kernel are separate arrays, so two different
+// singletons -- and a singleton against itself -- always read as "different"; the compare
+// kernel forces the diagonal, which the reference sets to 1.0 anyway, src/minHash.cpp:161).
+// D + 2 <= 65536 holds for every input with n <= DA_DICT_MAX_N = 131068, so 16 bit planes per
+// 32 hash functions carry the same information as the 32 planes of the raw values and the
+// bit-sliced compare does half the work.  Bit-exact by construction, not a sketch.
+//
+//   k_sig_transpose : sig[n][ld] -> sigT[n_hash][ldT]          (coalesced column access)
+//   k_dictionary    : one workgroup per hash function; LDS hash table over key partitions
+//   k_ids_to_planes : ids[n_hash][ldT] (uint16) -> bit planes, 16 words per 32-hash group,
+//                     row copy + pair-swapped column copy (layout of k_mh_compare<.., 16>)
+//   k_sig_to_planes : raw 32-plane layout from sig (n > DA_DICT_MAX_N, or dictionary overflow)
+#include "da_common.hpp"
+
+namespace da {
+namespace {
+
+// ------------------------------------------------------------- transpose --
+__global__ __launch_bounds__(256) void k_sig_transpose(const uint32_t *__restrict__ sig, int64_t ld_sig, int64_t n,
+                                                       int n_hash, uint32_t *__restrict__ sigT, int64_t ldT) {
+  __shared__ uint32_t t[64][65];
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  const int h0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;   // 64 x 4
+  for (int r = ly; r < 64; r += 4) {
+    const int64_t i = i0 + r;
+    const int h = h0 + lx;
+    t[r][lx] = (i < n && h < n_hash) ? sig[i * ld_sig + h] : 0u;
+  }
+  __syncthreads();
+  for (int r = ly; r < 64; r += 4) {
+    const int h = h0 + r;
+    const int64_t i = i0 + lx;
+    if (h < n_hash && i < ldT) sigT[(int64_t)h * ldT + i] = t[lx][r];
+  }
+}
+
+// ------------------------------------------------------------ dictionary --
+constexpr int DK_THREADS = 1024;
+constexpr int DK_SLOTS = 16384;        // LDS table slots per key partition (power of two)
+constexpr int DK_PART_KEYS = 8192;     // partitions are sized for <= 50 % load even if every key is distinct
+constexpr int DK_UNROLL = 8;           // independent loads in flight per thread
+
+// a bijection of uint32 (murmur3's finaliser): partition and slot are taken from the mixed key,
+// so the skew of min-hash VALUES (they crowd near 0) does not reach the table
+__device__ __forceinline__ uint32_t dk_mix(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ int dk_part(uint32_t z, int R) { return (int)__umulhi(z, (uint32_t)R); }
+__device__ __forceinline__ uint32_t dk_slot(uint32_t z) { return (z * 0x9e3779b1u) >> (32 - 14); }
+static_assert(DK_SLOTS == (1 << 14), "dk_slot assumes 2^14 slots");
+
+// status word: 0 ok, 1 a partition overflowed its table, 2 more than 65534 repeated values
+__global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__restrict__ sigT, int64_t ldT, int64_t n,
+                                                           int R, uint16_t *__restrict__ idsT, int64_t ld_ids,
+                                                           int *__restrict__ status) {
+  __shared__ uint32_t keys[DK_SLOTS];
+  __shared__ uint16_t vals[DK_SLOTS];
+  __shared__ uint32_t wsum[DK_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t *col = sigT + (int64_t)blockIdx.x * ldT;
+  uint16_t *ids = idsT + (int64_t)blockIdx.x * ld_ids;
+  uint32_t base = 0;       // dense ids handed out so far (uniform over the workgroup)
+  bool overflow = false;
+
+  for (int r = 0; r < R; ++r) {
+    // a mixed key that can never be inserted in this pass marks an empty slot: the smallest z
+    // of partition (r+1) % R  (R >= 2)
+    const uint32_t q = (uint32_t)((r + 1) % R);
+    const uint32_t EMPTY = (uint32_t)((((uint64_t)q << 32) + (uint32_t)R - 1) / (uint32_t)R);
+    for (int s = tid; s < DK_SLOTS; s += DK_THREADS) { keys[s] = EMPTY; vals[s] = 0; }
+    __syncthreads();
+
+    // ---- insert: first arrival claims a slot, every later arrival of the same key flags it
+    for (int64_t i0 = 0; i0 < n; i0 += (int64_t)DK_THREADS * DK_UNROLL) {
+      uint32_t z[DK_UNROLL];
+      bool act[DK_UNROLL];
+#pragma unroll
+      for (int u = 0; u < DK_UNROLL; ++u) {
+        const int64_t i = i0 + (int64_t)u * DK_THREADS + tid;
+        act[u] = i < n;
+        z[u] = dk_mix(act[u] ? col[i] : 0u);
+        act[u] = act[u] && dk_part(z[u], R) == r;
+      }
+#pragma unroll
+      for (int u = 0; u < DK_UNROLL; ++u) {
+        if (!act[u]) continue;
+        uint32_t s = dk_slot(z[u]);
+        for (int probes = 0;; ++probes) {
+          const uint32_t old = atomicCAS(&keys[s], EMPTY, z[u]);
+          if (old == EMPTY) break;
+          if (old == z[u]) { vals[s] = 1; break; }
+          s = (s + 1) & (DK_SLOTS - 1);
+          if (probes >= DK_SLOTS) { overflow = true; break; }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- number the repeated keys of this partition: base + exclusive scan over the slots
+    uint32_t mine = 0;
+    for (int s = tid; s < DK_SLOTS; s += DK_THREADS) mine += vals[s];
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < DK_THREADS / 64; ++w) {
+      const uint32_t v = wsum[w];
+      if (w < wave) before += v;
+      total += v;
+    }
+    uint32_t next = base + before + incl - mine;
+    for (int s = tid; s < DK_SLOTS; s += DK_THREADS) {
+      if (keys[s] == EMPTY) continue;
+      vals[s] = vals[s] ? (uint16_t)(next++) : (uint16_t)0xFFFFu;
+    }
+    base += total;
+    __syncthreads();
+
+    // ---- look every key of the partition up again and emit its code
+    for (int64_t i0 = 0; i0 < n; i0 += (int64_t)DK_THREADS * DK_UNROLL) {
+      uint32_t z[DK_UNROLL];
+      bool act[DK_UNROLL];
+#pragma unroll
+      for (int u = 0; u < DK_UNROLL; ++u) {
+        const int64_t i = i0 + (int64_t)u * DK_THREADS + tid;
+        act[u] = i < n;
+        z[u] = dk_mix(act[u] ? col[i] : 0u);
+        act[u] = act[u] && dk_part(z[u], R) == r;
+      }
+#pragma unroll
+      for (int u = 0; u < DK_UNROLL; ++u) {
+        if (!act[u]) continue;
+        uint32_t s = dk_slot(z[u]);
+        uint16_t id = 0xFFFFu;
+        for (int probes = 0; probes <= DK_SLOTS; ++probes) {
+          const uint32_t cur = keys[s];
+          if (cur == z[u]) { id = vals[s]; break; }
+          if (cur == EMPTY) break;                       // only after an overflow
+          s = (s + 1) & (DK_SLOTS - 1);
+        }
+        ids[i0 + (int64_t)u * DK_THREADS + tid] = id;
+      }
+    }
+    __syncthreads();
+  }
+  if (overflow) atomicMax(status, 1);
+  if (tid == 0 && base > 65534u) atomicMax(status, 2);
+}
+
+// ----------------------------------------------------------- bit planes --
+// 64 sequences x all hash functions per workgroup.  Per chunk of 64 hash functions the 64 x 64
+// uint16 code tile is staged in LDS; a wave then owns a sequence and its lane l holds the code of
+// hash function h0 + l, so one 64-bit ballot per bit is plane p of two adjacent 32-hash groups.
+// Singletons (0xFFFF): row copy gets 0xFFFE, column copy 0xFFFF -- they differ in plane 0 only.
+__global__ __launch_bounds__(256) void k_ids_to_planes(const uint16_t *__restrict__ idsT, int64_t ld_ids, int64_t n,
+                                                       int n_hash, uint32_t *__restrict__ planes, int64_t ld_planes) {
+  __shared__ uint16_t tile[64][66];
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half_ld = (int)(ld_planes >> 1);
+  const int ngroup = (n_hash + 31) / 32;
+  for (int h0 = 0; h0 < ngroup * 32; h0 += 64) {
+    __syncthreads();
+    for (int r = wave; r < 64; r += 4) {       // row r of the tile = hash function h0 + r, 64 sequences (128 B)
+      const int h = h0 + r;
+      const int64_t i = i0 + lane;
+      tile[r][lane] = (h < n_hash && i < n) ? idsT[(int64_t)h * ld_ids + i] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int sq = wave; sq < 64; sq += 4) {
+      const int64_t i = i0 + sq;
+      if (i >= n) break;                         // wave-uniform
+      const uint32_t v = tile[lane][sq];
+      const bool single = (v == 0xFFFFu) && (h0 + lane < n_hash);
+      const uint32_t va = single ? 0xFFFEu : v;
+      uint32_t wa = 0, wb = 0;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const unsigned long long m = __ballot((va >> p) & 1u);
+        const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+        wa = ((lane & 31) == p) ? half : wa;
+      }
+      {
+        const unsigned long long m = __ballot(v & 1u);     // plane 0 of the column copy
+        const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+        wb = ((lane & 31) == 0) ? half : wa;
+      }
+      const int g = (h0 >> 5) + (lane >> 5);
+      const int p = lane & 31;
+      if (p < 16 && g < ngroup) {
+        uint32_t *prow = planes + i * ld_planes;
+        prow[g * 16 + p] = wa;
+        prow[half_ld + g * 16 + (p ^ 1)] = wb;     // pair-swapped copy (see k_mh_compare)
+      }
+    }
+  }
+}
+
+// raw values, 32 planes per group: the layout k_minhash_signatures also writes
+__global__ __launch_bounds__(256) void k_sig_to_planes(const uint32_t *__restrict__ sig, int64_t ld_sig, int64_t n,
+                                                       int n_hash, uint32_t *__restrict__ planes, int64_t ld_planes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const int half_ld = (int)(ld_planes >> 1);
+  const int ngroup = (n_hash + 31) / 32;
+  const uint32_t *row = sig + i * ld_sig;
+  uint32_t *prow = planes + i * ld_planes;
+  for (int h0 = 0; h0 < ngroup * 32; h0 += 64) {
+    const int h = h0 + lane;
+    const uint32_t v = (h < n_hash) ? row[h] : 0u;
+    uint32_t w = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      const unsigned long long m = __ballot((v >> p) & 1u);
+      const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+      w = ((lane & 31) == p) ? half : w;
+    }
+    if (h < ngroup * 32) {
+      prow[h] = w;
+      prow[half_ld + (h ^ 1)] = w;
+    }
+  }
+}
+
+}  // namespace
+
+static int64_t dict_ldT(int64_t n) { return ceil_div(n, 64) * 64; }
+
+size_t mh_planes_workspace_bytes(int64_t n, int n_hash) {
+  if (n <= 0 || n_hash <= 0 || n > DA_DICT_MAX_N) return 256;
+  const size_t ldT = (size_t)dict_ldT(n);
+  return (size_t)n_hash * ldT * 4 + (size_t)n_hash * ldT * 2 + 256;
+}
+
+// d_status (inside the workspace) is left for the caller to read after the stream has drained
+int launch_mh_dictionary_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work,
+                                uint32_t *d_planes, int64_t ld_planes, int **d_status_out, hipStream_t stream) {
+  const int64_t ldT = dict_ldT(n);
+  uint32_t *sigT = static_cast<uint32_t *>(d_work);
+  uint16_t *idsT = reinterpret_cast<uint16_t *>(sigT + (size_t)n_hash * ldT);
+  int *status = reinterpret_cast<int *>(reinterpret_cast<char *>(d_work) + (size_t)n_hash * ldT * 6);
+  status = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(status) + 63) & ~(uintptr_t)63);
+  *d_status_out = status;
+  DA_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream));
+  hipLaunchKernelGGL(k_sig_transpose, dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_hash, 64)), dim3(256), 0,
+                     stream, d_sig, ld_sig, n, n_hash, sigT, ldT);
+  int R = (int)ceil_div(n, DK_PART_KEYS);
+  if (R < 2) R = 2;
+  hipLaunchKernelGGL(k_dictionary, dim3((unsigned)n_hash), dim3(DK_THREADS), 0, stream, sigT, ldT, n, R, idsT, ldT, status);
+  hipLaunchKernelGGL(k_ids_to_planes, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, stream, idsT, ldT, n, n_hash,
+                     d_planes, ld_planes);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, uint32_t *d_planes,
+                         int64_t ld_planes, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sig_to_planes, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, d_sig, ld_sig, n, n_hash,
+                     d_planes, ld_planes);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+}  // namespace da

@@ -260,7 +260,9 @@ __host__ __device__ inline int64_t count_tiles(int TR, int T, bool symmetric) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-template <bool SYM, bool F64>
+// PL = bit planes per group of 32 hash functions: 32 (raw uint32 values) or 16 (dictionary codes of
+// dict_kernels.hip: same equalities off the diagonal, half the planes; the diagonal is forced).
+template <bool SYM, bool F64, int PL>
 __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const uint32_t *__restrict__ planes, int64_t ld_p, int64_t n, int n_hash, int64_t row_begin,
     int64_t row_end, int tile_stride, int upper_only, int TR, void *__restrict__ out_v, int64_t ld,
@@ -400,20 +402,8 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   };
 
   const int ngroup = (n_hash + K2_GROUP - 1) / K2_GROUP;
-  const int nstage = 2 * ngroup;
-  issue(0);
-  issue(1);
-  for (int g = 0; g < ngroup; ++g) {
-    // wait_stage: this wave's copies for the stage have landed; the barrier: so have everyone's, and
-    // nobody still reads the ring slot the next issue() overwrites (it was consumed two stages ago).
-    wait_stage(true);                       // stage 2g+1 was issued after stage 2g
-    __syncthreads();
-    if (2 * g + 2 < nstage) issue(2 * g + 2);
-    compute(2 * g);
-    wait_stage(2 * g + 2 < nstage);         // stage 2g+2 (if any) is younger than stage 2g+1
-    __syncthreads();
-    if (2 * g + 3 < nstage) issue(2 * g + 3);
-    compute(2 * g + 1);
+  const int nstage = (PL / K2_SP) * ngroup;
+  auto count_group = [&]() {
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -423,6 +413,43 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     for (int r = 0; r < 8; ++r)
 #pragma unroll
       for (int c = 0; c < 8; ++c) d[r][c] = 0;
+  };
+  // wait_stage: this wave's copies for the stage have landed; the barrier: so have everyone's, and
+  // nobody still reads the ring slot the next issue() overwrites (it was consumed two stages ago).
+  issue(0);
+  if (nstage > 1) issue(1);
+  if (PL == 32) {
+    for (int g = 0; g < ngroup; ++g) {
+      wait_stage(true);                       // stage 2g+1 was issued after stage 2g
+      __syncthreads();
+      if (2 * g + 2 < nstage) issue(2 * g + 2);
+      compute(2 * g);
+      wait_stage(2 * g + 2 < nstage);         // stage 2g+2 (if any) is younger than stage 2g+1
+      __syncthreads();
+      if (2 * g + 3 < nstage) issue(2 * g + 3);
+      compute(2 * g + 1);
+      count_group();
+    }
+  } else {
+    for (int g = 0; g < ngroup; ++g) {        // one 16-plane stage per group
+      wait_stage(g + 1 < nstage);
+      __syncthreads();
+      if (g + 2 < nstage) issue(g + 2);
+      compute(g);
+      count_group();
+    }
+    // dictionary codes make a sequence differ from itself wherever it holds a singleton value:
+    // the diagonal is n_hash matches by definition (src/minHash.cpp:161)
+    if (I0 - J0 < K2_TILE && J0 - I0 < K2_TILE) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
+          const int64_t gj = J0 + 32 * (c >> 1) + 2 * tx + (c & 1);
+          if (gi == gj) mis[r][c >> 1] &= (c & 1) ? 0x0000ffffu : 0xffff0000u;
+        }
+    }
   }
   auto matches = [&](int r, int c) -> uint32_t {  // reference src/minHash.cpp:168-173
     return (uint32_t)n_hash - ((mis[r][c >> 1] >> ((c & 1) * 16)) & 0xffffu);
@@ -562,9 +589,10 @@ int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_
 
 int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
-                      void *d_out, int64_t ld, hipStream_t stream, int tile_stride, bool upper_only,
+                      void *d_out, int64_t ld, hipStream_t stream, int plane_bits, int tile_stride, bool upper_only,
                       int fold_q, int64_t fold_w) {
   if (row_end <= row_begin) return DA_OK;
+  if (plane_bits != 16 && plane_bits != 32) return fail(DA_ERR_BAD_ARG, "plane_bits must be 16 or 32 (got %d)", plane_bits);
   const int T = (int)ceil_div(n, K2_TILE);
   const int TR = (int)ceil_div(ceil_div(row_end - row_begin, K2_TILE), tile_stride);
   const int64_t ntiles = count_tiles(TR, T, symmetric);
@@ -576,11 +604,16 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
   const int64_t nblocks = symmetric ? per_xcd * 8 : 8 * ceil_div(ceil_div(TR, band), 8) * (int64_t)band * T;
   if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
-#define DA_K2(SYM, F64)                                                                              \
-  hipLaunchKernelGGL((k_mh_compare<SYM, F64>), grid, block, 0, stream, d_planes, ld_planes, n, n_hash, \
+#define DA_K2(SYM, F64, PL)                                                                              \
+  hipLaunchKernelGGL((k_mh_compare<SYM, F64, PL>), grid, block, 0, stream, d_planes, ld_planes, n, n_hash, \
                      row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w, band)
-  if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true); else DA_K2(true, false); }
-  else           { if (kind == DA_OUT_F64) DA_K2(false, true); else DA_K2(false, false); }
+#define DA_K2_PL(PL)                                                                     \
+  do {                                                                                   \
+    if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true, PL); else DA_K2(true, false, PL); } \
+    else           { if (kind == DA_OUT_F64) DA_K2(false, true, PL); else DA_K2(false, false, PL); } \
+  } while (0)
+  if (plane_bits == 16) DA_K2_PL(16); else DA_K2_PL(32);
+#undef DA_K2_PL
 #undef DA_K2
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;

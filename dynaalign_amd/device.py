@@ -5,6 +5,8 @@ torch.distributed); every computation is a launch of the library's HIP kernels
 through the ``da_dev_*`` entry points of include/dynaalign.h.  Calls are
 asynchronous on ``torch.cuda.current_stream()``.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -45,25 +47,78 @@ def planes_ld(n_hash):
     return int(_capi.load().da_planes_ld(int(n_hash)))
 
 
-def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=True):
-    """K1.  Returns (sig, planes): int32 tensors (n, sig_ld(n_hash)) and (n, planes_ld(n_hash)).
-    `sig` holds the uint32 signatures in columns [0, n_hash); `planes` the same data bit-transposed
-    in groups of 32 hash functions (plus a pair-swapped copy) -- the operand of mh_compare (None if
-    want_planes is False)."""
+class Planes:
+    """Operand of mh_compare: the bit-plane tensor plus the number of planes it holds per group of
+    32 hash functions (16: dictionary codes from da_dev_mh_planes, 32: raw signature bits)."""
+
+    def __init__(self, tensor, bits):
+        self.tensor, self.bits = tensor, int(bits)
+
+    def data_ptr(self):
+        return self.tensor.data_ptr()
+
+    def stride(self, d):
+        return self.tensor.stride(d)
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @property
+    def is_cuda(self):
+        return self.tensor.is_cuda
+
+
+def planes_workspace_bytes(n, n_hash):
+    return int(_capi.load().da_mh_planes_workspace_bytes(int(n), int(n_hash)))
+
+
+def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=True, raw_planes=False, work=None):
+    """K1 (+ K1b).  Returns (sig, planes): `sig` is the int32 tensor (n, sig_ld(n_hash)) holding the uint32
+    signatures in columns [0, n_hash); `planes` is the Planes operand of mh_compare (None if want_planes is
+    False): the signatures' dictionary codes, bit-transposed, 16 planes per 32 hash functions
+    (da_dev_mh_planes; synchronises the stream once), or with raw_planes=True the 32 raw bit planes K1 writes
+    itself.  `planes` / `work` may be preallocated: (n, planes_ld(n_hash)) int32 and
+    planes_workspace_bytes(n, n_hash) uint8."""
     lib = _capi.load()
     if not torch.is_tensor(seeds):
         seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32).copy()).to(ds.residues.device)
     _require_cuda(ds.residues, "residues")
     ld = sig_ld(n_hash) if n_hash > 0 else 32
+    dev = ds.residues.device
     if out is None:
-        out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
+        out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=dev)
+    if isinstance(planes, Planes):
+        planes = planes.tensor
     if planes is None and want_planes:
-        planes = torch.empty((max(ds.n, 1), 2 * ld), dtype=torch.int32, device=ds.residues.device)
+        planes = torch.empty((max(ds.n, 1), 2 * ld), dtype=torch.int32, device=dev)
+    inline = planes is not None and raw_planes
     _capi.check(lib.da_dev_minhash_signatures(ds.residues.data_ptr(), ds.offsets.data_ptr(), ds.n, ds.total,
                                               ds.max_len, int(k), int(n_hash), seeds.data_ptr(), out.data_ptr(),
-                                              out.stride(0), None if planes is None else planes.data_ptr(),
-                                              0 if planes is None else planes.stride(0), _stream()))
-    return out, planes
+                                              out.stride(0), planes.data_ptr() if inline else None,
+                                              planes.stride(0) if inline else 0, _stream()))
+    if planes is None:
+        return out, None
+    if inline:
+        return out, Planes(planes, 32)
+    return out, mh_planes(out, ds.n, n_hash, planes, work)
+
+
+def mh_planes(sig, n, n_hash, planes=None, work=None):
+    """K1b.  Signature tensor -> Planes operand (dictionary codes, 16 planes per group, when n <= 131068;
+    raw 32 planes otherwise).  Synchronises the current stream once on the 16-plane route."""
+    lib = _capi.load()
+    _require_cuda(sig, "signatures")
+    if isinstance(planes, Planes):
+        planes = planes.tensor
+    if planes is None:
+        planes = torch.empty((max(n, 1), planes_ld(n_hash)), dtype=torch.int32, device=sig.device)
+    if work is None:
+        work = torch.empty(planes_workspace_bytes(n, n_hash), dtype=torch.uint8, device=sig.device)
+    bits = ctypes.c_int(0)
+    _capi.check(lib.da_dev_mh_planes(sig.data_ptr(), sig.stride(0), n, int(n_hash), work.data_ptr(), work.numel(),
+                                     planes.data_ptr(), planes.stride(0), ctypes.byref(bits), _stream()))
+    return Planes(planes, bits.value)
 
 
 def _alloc_out(rows, n, kind, device, out):
@@ -73,17 +128,17 @@ def _alloc_out(rows, n, kind, device, out):
     return torch.empty((max(rows, 1), max(n, 1)), dtype=dt, device=device)
 
 
-def mh_compare(sig, n, n_hash, row_begin=0, row_end=None, symmetric=None, kind=DA_OUT_F64, out=None):
-    """K2.  `sig` is the bit-plane tensor from minhash_signatures.  Rows [row_begin,row_end) of the
+def mh_compare(planes, n, n_hash, row_begin=0, row_end=None, symmetric=None, kind=DA_OUT_F64, out=None):
+    """K2.  `planes` is the Planes operand from minhash_signatures.  Rows [row_begin,row_end) of the
     n x n similarity (float64) or match-count (uint16 in an int16 tensor) matrix."""
     lib = _capi.load()
-    _require_cuda(sig, "bit planes")
+    _require_cuda(planes, "bit planes")
     row_end = n if row_end is None else row_end
     if symmetric is None:
         symmetric = (row_begin == 0 and row_end == n)
-    out = _alloc_out(row_end - row_begin, n, kind, sig.device, out)
-    _capi.check(lib.da_dev_mh_compare(sig.data_ptr(), sig.stride(0), n, int(n_hash), row_begin, row_end,
-                                      1 if symmetric else 0, kind, out.data_ptr(), out.stride(0), _stream()))
+    out = _alloc_out(row_end - row_begin, n, kind, planes.device, out)
+    _capi.check(lib.da_dev_mh_compare(planes.data_ptr(), planes.stride(0), planes.bits, n, int(n_hash), row_begin,
+                                      row_end, 1 if symmetric else 0, kind, out.data_ptr(), out.stride(0), _stream()))
     return out
 
 

@@ -141,6 +141,25 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
                               uint32_t *d_sig, int64_t ld_sig,
                               uint32_t *d_planes, int64_t ld_planes, void *stream);
 
+/* K1b: signatures -> operand of the compare kernel.  The compare only asks "equal or not" per
+ * hash function (src/minHash.cpp:168-173), so each column of d_sig is re-coded exactly: values
+ * occurring >= 2 times get dense 16-bit ids, values occurring once get codes that never match
+ * (0xFFFE row side / 0xFFFF column side).  That needs 16 instead of 32 bit planes per group of
+ * 32 hash functions and halves the compare's work; it is exact for every input with
+ * n <= 131068 (at most n/2 repeated values per column).  Larger n -- or the never-observed
+ * overflow of the dictionary's LDS table -- produce the raw 32-plane layout instead.
+ *   d_planes      : n rows of ld_planes (>= da_planes_ld(n_hash), multiple of 64) uint32.
+ *                   16-plane layout: word 16g+p = bit p of the codes of hash functions
+ *                   32g..32g+31; column copy (planes pair-swapped) at word ld_planes/2.
+ *   d_work        : da_mh_planes_workspace_bytes(n, n_hash) bytes of scratch, 256-byte aligned
+ *   plane_bits_out: 16 or 32 -- pass it to da_dev_mh_compare[_shard].
+ * Synchronises `stream` once (reads the dictionary's status word) when it takes the 16-bit route.
+ * The environment variable DYNAALIGN_PLANE_BITS=32 forces the raw layout (debugging aid). */
+size_t da_mh_planes_workspace_bytes(int64_t n, int n_hash);
+int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
+                     void *d_work, size_t work_bytes, uint32_t *d_planes, int64_t ld_planes,
+                     int *plane_bits_out, void *stream);
+
 /* K2: all-pairs signature compare (bit-sliced: OR over planes of a XOR b, then
  * popcount; matches = n_hash - mismatches).
  * Computes rows [row_begin,row_end) of the n x n result into d_out, which
@@ -150,8 +169,9 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
  *                    (direct + mirrored), like src/minHash.cpp:175-176.
  *   symmetric == 0 : every (i,j) of the row block is compared (row-sharding).
  * kind selects double or uint16 counts.  Diagonal = 1.0 / n_hash.
- * d_planes: 16-byte aligned bit-plane matrix from da_dev_minhash_signatures. */
-int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
+ * d_planes: 16-byte aligned bit-plane matrix from da_dev_mh_planes (plane_bits as it reported) or
+ * from da_dev_minhash_signatures (plane_bits = 32). */
+int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, int symmetric,
                       int kind, void *d_out, int64_t ld, void *stream);
 
@@ -185,7 +205,7 @@ int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64
  * single-process); the math per pair is unchanged. */
 int64_t da_shard_rows(int64_t n, int world, int is_nw);
 int64_t da_shard_ld(int64_t n, int world, int is_nw);
-int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
+int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash,
                             int rank, int world, uint16_t *d_local, int64_t ld, void *stream);
 int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len,
                     int matrix_id, int gap_open, int gap_ext, int rank, int world,

@@ -1,0 +1,151 @@
+"""GPU tests of K1b (dict_kernels.hip): the exact 16-bit re-coding of the signatures.
+
+The compare kernel must give the same match counts from the dictionary codes (16 planes per 32
+hash functions) as from the raw signature bits (32 planes), and both must equal the oracle
+(reference src/minHash.cpp:160-178).  Inputs are chosen to stress what the re-coding relies on:
+singletons (uniform peptides: most values occur once), repeated values (h3n2-like windows,
+duplicated sequences), the all-equal column (sequences shorter than k: UINT32_MAX everywhere),
+row blocks that cut the diagonal at arbitrary offsets, and the id-count worst case n = 131068
+with every value occurring exactly twice."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def da(built):
+    import dynaalign_amd
+    from dynaalign_amd import _capi
+    assert _capi.load().da_device_count() > 0
+    return dynaalign_amd
+
+
+def _counts(sig_h):
+    return np.stack([(row[None, :] == sig_h).sum(1) for row in sig_h]).astype(np.uint16)
+
+
+def _planes_both(da, res, off, k, n_hash, seed=12345):
+    from dynaalign_amd import device
+    seeds = da.hash_family_seeds(seed, n_hash)
+    ds = device.DeviceSequences(res, off)
+    sig, p16 = device.minhash_signatures(ds, k, n_hash, seeds)
+    _, p32 = device.minhash_signatures(ds, k, n_hash, seeds, raw_planes=True)
+    assert p16.bits == 16 and p32.bits == 32
+    return ds.n, sig[:, :n_hash].cpu().numpy().view(np.uint32), p16, p32
+
+
+@pytest.mark.parametrize("gen,n", [("uniform_peptides", 1), ("uniform_peptides", 2), ("uniform_peptides", 63),
+                                   ("uniform_peptides", 64), ("uniform_peptides", 65), ("uniform_peptides", 1000),
+                                   ("h3n2_like", 129), ("h3n2_like", 1500), ("uniform_peptides", 9000)])
+@pytest.mark.parametrize("n_hash", [500, 31, 64])
+def test_codes_give_the_counts_of_the_raw_signatures(da, gen, n, n_hash):
+    from dynaalign_amd import device, synth, _capi
+    if n >= 9000 and n_hash != 500:
+        pytest.skip("one large case is enough")
+    res, off = getattr(synth, gen)(n, 20)
+    n, sig_h, p16, p32 = _planes_both(da, res, off, 4, n_hash)
+    c16 = device.mh_compare(p16, n, n_hash, kind=_capi.DA_OUT_COMPACT).cpu().numpy().view(np.uint16)
+    c32 = device.mh_compare(p32, n, n_hash, kind=_capi.DA_OUT_COMPACT).cpu().numpy().view(np.uint16)
+    assert np.array_equal(c16, c32)
+    if n <= 1500:
+        assert np.array_equal(c16, _counts(sig_h))
+    f16 = device.mh_compare(p16, n, n_hash).cpu().numpy()
+    f32 = device.mh_compare(p32, n, n_hash).cpu().numpy()
+    assert np.array_equal(f16.view(np.uint64), f32.view(np.uint64))
+    assert np.all(np.diagonal(f16) == 1.0)
+
+
+def test_duplicates_short_sequences_and_identical_input(da):
+    """duplicated sequences (every value repeated), sequences shorter than k (UINT32_MAX in every
+    column, reference src/minHash.cpp:98-103,140) and an input of identical sequences"""
+    import dynaalign_amd as dam
+    rng = np.random.RandomState(3)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    base = ["".join(map(chr, alpha[rng.randint(0, 20, 20)])) for _ in range(150)]
+    seqs = base + base[:70] + ["AC", "A", "", "ACD"] * 5 + ["MKTIIALSYIFCLVFA"] * 40
+    rng.shuffle(seqs)
+    seeds = dam.hash_family_seeds(99, 200)
+    rc, want = O.similarity_mh(seqs, 4, 200, seeds)
+    assert rc == 0
+    got = dam.similarityMH(seqs, 4, 200, seed=99)
+    assert np.array_equal(np.asarray(got).view(np.uint64), want.view(np.uint64))
+    same = ["MKTIIALSYIFCLVFAQK"] * 300
+    got = dam.similarityMH(same, 4, 50, seed=1)
+    assert np.all(np.asarray(got) == 1.0)
+
+
+@pytest.mark.parametrize("row_begin,row_end", [(0, 700), (5, 133), (127, 129), (128, 640), (300, 301), (693, 700)])
+def test_row_blocks_keep_the_diagonal(da, row_begin, row_end):
+    """rectangular mode: the forced diagonal must follow arbitrary row offsets"""
+    from dynaalign_amd import device, synth, _capi
+    res, off = synth.uniform_peptides(700, 20)
+    n, sig_h, p16, p32 = _planes_both(da, res, off, 4, 100)
+    want = _counts(sig_h)[row_begin:row_end]
+    for p in (p16, p32):
+        got = device.mh_compare(p, n, 100, row_begin, row_end, False, _capi.DA_OUT_COMPACT)
+        assert np.array_equal(got.cpu().numpy().view(np.uint16), want)
+
+
+def test_host_path_same_with_raw_planes(da):
+    """DYNAALIGN_PLANE_BITS=32 (raw signature bits) and the default (dictionary codes) agree bit for bit"""
+    from dynaalign_amd import synth
+    res, off = synth.h3n2_like(2500, 20)
+    seqs = synth.to_strings(res, off)
+    a = np.asarray(da.similarityMH(seqs, 4, 500, seed=12345))
+    thr_a, ei_a, ej_a, ew_a = da.similarityMH_edges(seqs, 4, 500, 0.8, seed=12345)
+    os.environ["DYNAALIGN_PLANE_BITS"] = "32"
+    try:
+        b = np.asarray(da.similarityMH(seqs, 4, 500, seed=12345))
+        thr_b, ei_b, ej_b, ew_b = da.similarityMH_edges(seqs, 4, 500, 0.8, seed=12345)
+    finally:
+        del os.environ["DYNAALIGN_PLANE_BITS"]
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert thr_a == thr_b and np.array_equal(ei_a, ei_b) and np.array_equal(ej_a, ej_b) and np.array_equal(ew_a, ew_b)
+
+
+def test_worst_case_id_count(da):
+    """n = 131068 (the largest n the 16-bit codes are guaranteed for), every sequence present exactly
+    twice: close to n/2 repeated values per column.  Checked through properties on the device."""
+    import torch
+    from dynaalign_amd import device, synth, _capi
+    n, n_hash = 131068, 64
+    res, off = synth.uniform_peptides(n // 2, 20, seed=21)
+    res2 = np.concatenate([res[:off[-1]], res[:off[-1]]])
+    off2 = np.concatenate([off, off[1:] + off[-1]])
+    seeds = da.hash_family_seeds(5, n_hash)
+    ds = device.DeviceSequences(res2, off2)
+    assert ds.n == n
+    # k = 8: 13 shingles out of 20^8 per sequence, so nearly every sequence has its own value in a column
+    sig, p16 = device.minhash_signatures(ds, 8, n_hash, seeds)
+    assert p16.bits == 16
+    sig_h = sig[:, :n_hash].cpu().numpy().view(np.uint32)
+    cnt = device.mh_compare(p16, n, n_hash, kind=_capi.DA_OUT_COMPACT)        # 34 GB
+    want_total = 0
+    most = 0
+    for h in range(n_hash):
+        _, c = np.unique(sig_h[:, h], return_counts=True)
+        want_total += int((c.astype(np.int64) ** 2).sum())
+        most = max(most, int((c >= 2).sum()))
+    assert most > 60000                                                       # the test does exercise large id counts
+    got_total = 0
+    for r0 in range(0, n, 8192):
+        got_total += int(cnt[r0:r0 + 8192].to(torch.int32).sum(dtype=torch.int64).item())
+    assert got_total == want_total
+    assert bool((torch.diagonal(cnt) == n_hash).all())
+    half = n // 2
+    assert bool((torch.diagonal(cnt, offset=half) == n_hash).all())           # a sequence and its copy
+    for r0 in (0, 65530, 131000):
+        want = np.stack([(sig_h[i][None, :] == sig_h).sum(1) for i in range(r0, r0 + 8)]).astype(np.int16)
+        assert np.array_equal(cnt[r0:r0 + 8].cpu().numpy(), want)
+    del cnt
+    # beyond the guarantee the library must switch to the raw planes by itself
+    res3 = np.concatenate([res2, res[:20 * 4]])
+    off3 = np.concatenate([off2, off2[-1] + 20 * np.arange(1, 5)])
+    ds3 = device.DeviceSequences(res3, off3)
+    _, p = device.minhash_signatures(ds3, 8, n_hash, seeds)
+    assert p.bits == 32
