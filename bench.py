@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--no-nw", action="store_true", help="skip the similarityNW measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-edges", action="store_true", help="skip the threshold + edge-list measurement")
-    ap.add_argument("--plane-bits", type=int, default=16, choices=[16, 32],
-                    help="16: compare the signatures' exact dictionary codes (default); 32: raw signature bits")
+    ap.add_argument("--plane-bits", type=int, default=0, choices=[0, 12, 16, 32],
+                    help="0: compare the signatures' exact dictionary codes with as few bit planes as the data needs "
+                         "(default); 12 / 16: at least that many code planes; 32: raw signature bits")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per baseline leg")
     return ap.parse_args()
 
@@ -159,23 +160,17 @@ def main():
     ds = device.DeviceSequences(res, off, "cuda")
     d_seeds = torch.from_numpy(seeds.view(np.int32).copy()).cuda()
     sig = torch.empty((n, device.sig_ld(n_hash)), dtype=torch.int32, device="cuda")
-    planes = torch.empty((n, device.planes_ld(n_hash)), dtype=torch.int32, device="cuda")
+    planes = torch.empty(device.planes_words(n, n_hash), dtype=torch.int32, device="cuda")
     pwork = torch.empty(device.planes_workspace_bytes(n, n_hash), dtype=torch.uint8, device="cuda")
-    raw = a.plane_bits == 32
     state = {"bits": 32}
 
     def signatures_and_planes(e=None):
-        """K1 (signatures) + K1b (dictionary codes -> 16 bit planes per 32 hash functions); --plane-bits 32
-        keeps the raw 32-plane operand K1 writes itself."""
-        if raw:
-            pl = device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, planes=planes, raw_planes=True)[1]
-            if e is not None:
-                e.record()
-            return pl
+        """K1 (signatures) + K1b (exact dictionary codes -> 8 / 12 / 16 bit planes per 32 hash functions);
+        --plane-bits 32 keeps the raw signature bits, 12 / 16 set a lower bound on the code planes."""
         device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, want_planes=False)
         if e is not None:
             e.record()
-        pl = device.mh_planes(sig, n, n_hash, planes, pwork)
+        pl = device.mh_planes(sig, n, n_hash, planes, pwork, a.plane_bits)
         state["bits"] = pl.bits
         return pl
     out = torch.empty((n, n), dtype=torch.float64, device="cuda")
@@ -245,7 +240,7 @@ def main():
     else:
         tiles = sum(T - t for t in range(rank, T, world))
         bytes_k2 = n * planes_row_bytes + tiles * 128 * 128 * 2   # this rank's uint16 tiles
-    lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 16|32 planes)
+    lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
     traffic = pmc_traffic("k_mh_compare<true, true, %d>" % plane_bits) if world == 1 else None
     roof = {"kernel": "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,

@@ -35,11 +35,11 @@ SIGNATURES = {
     "da_similarity_nw": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _vp]),
     "da_nw_pairs": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _i64, _i64, _vp, _vp, _vp]),
     "da_sig_ld": (_i64, [_i32]),
-    "da_planes_ld": (_i64, [_i32]),
-    "da_dev_minhash_signatures": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "da_dev_minhash_signatures": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "da_mh_planes_words": (_i64, [_i64, _i32]),
     "da_mh_planes_workspace_bytes": (_sz, [_i64, _i32]),
-    "da_dev_mh_planes": (_i32, [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _i64, _vp, _vp]),
-    "da_dev_mh_compare": (_i32, [_vp, _i64, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "da_dev_mh_planes": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _sz, _vp, _i64, _vp, _vp]),
+    "da_dev_mh_compare": (_i32, [_vp, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "da_similarity_mh_edges": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, C.c_double, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -51,7 +51,7 @@ SIGNATURES = {
     "da_matrix_id": (_i32, [C.c_char_p]),
     "da_shard_rows": (_i64, [_i64, _i32, _i32]),
     "da_shard_ld": (_i64, [_i64, _i32, _i32]),
-    "da_dev_mh_compare_shard": (_i32, [_vp, _i64, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "da_dev_mh_compare_shard": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_shard": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_finalize_shards": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_symmetrize": (_i32, [_vp, _i64, _i64, _i32, _vp]),

@@ -250,59 +250,67 @@ int da_matrix_id(const char *matrix_name) {
 
 int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n,
                               int64_t total_residues, int64_t max_len, int k, int n_hash,
-                              const uint32_t *d_seeds, uint32_t *d_sig, int64_t ld_sig,
-                              uint32_t *d_planes, int64_t ld_planes, void *stream) {
+                              const uint32_t *d_seeds, uint32_t *d_sig, int64_t ld_sig, void *stream) {
   (void)total_residues; (void)max_len;
   int rc = validate_mh(n, k, n_hash);
   if (rc != DA_OK) return rc;
   if (!d_residues || !d_offsets || !d_seeds || !d_sig) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
   if (ld_sig < n_hash) return fail(DA_ERR_BAD_ARG, "ld_sig (%lld) < n_hash (%d)", (long long)ld_sig, n_hash);
-  if (d_planes && (ld_planes < 2 * sig_ld_for(n_hash) || (ld_planes & 63)))
-    return fail(DA_ERR_BAD_ARG, "ld_planes must be a multiple of 64 and >= da_planes_ld(n_hash) = %lld",
-                (long long)(2 * sig_ld_for(n_hash)));
-  return launch_minhash_signatures(d_residues, d_offsets, n, k, n_hash, d_seeds, d_sig, ld_sig, d_planes,
-                                   ld_planes, static_cast<hipStream_t>(stream));
+  return launch_minhash_signatures(d_residues, d_offsets, n, k, n_hash, d_seeds, d_sig, ld_sig,
+                                   static_cast<hipStream_t>(stream));
 }
 
 // signatures -> compare operand: dictionary codes (16 planes / group) when n allows, raw values otherwise
-static int forced_plane_bits() {
+static int env_plane_bits() {   // DYNAALIGN_PLANE_BITS: 32 = raw planes, 12 / 16 = at least that many code planes
   const char *e = getenv("DYNAALIGN_PLANE_BITS");
-  return (e && atoi(e) == 32) ? 32 : 0;
+  const int v = e ? atoi(e) : 0;
+  return (v == 32 || v == 16 || v == 12) ? v : 0;
 }
-static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work, size_t work_bytes,
-                        uint32_t *d_planes, int64_t ld_planes, int *bits_out, hipStream_t stream) {
+// min_bits: 0 = as few code planes as the data needs, 12 / 16 = at least that many, 32 = raw planes
+static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, int min_bits, void *d_work,
+                        size_t work_bytes, uint32_t *d_planes, int *bits_out, hipStream_t stream) {
   int rc;
-  if (n <= DA_DICT_MAX_N && forced_plane_bits() != 32) {
+  const int env = env_plane_bits();
+  if (env > min_bits) min_bits = env;
+  if (n <= DA_DICT_MAX_N && min_bits != 32) {
     if (!d_work || work_bytes < mh_planes_workspace_bytes(n, n_hash))
       return fail(DA_ERR_BAD_ARG, "workspace smaller than da_mh_planes_workspace_bytes(n, n_hash)");
     int *d_status = nullptr;
-    if ((rc = launch_mh_dictionary_planes(d_sig, ld_sig, n, n_hash, d_work, d_planes, ld_planes, &d_status, stream)) != DA_OK)
-      return rc;
-    int status = 0;
-    DA_HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if ((rc = launch_mh_dictionary(d_sig, ld_sig, n, n_hash, d_work, &d_status, stream)) != DA_OK) return rc;
+    int status[2] = {0, 0};
+    DA_HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, stream));
     DA_HIP_TRY(hipStreamSynchronize(stream));
-    if (status == 0) { *bits_out = 16; return DA_OK; }
+    if (status[0] == 0) {
+      int bits = mh_plane_bits_for(status[1]);
+      if (bits < min_bits) bits = min_bits;
+      *bits_out = bits;
+      return launch_ids_to_planes(d_work, n, n_hash, bits, d_planes, stream);
+    }
   }
   *bits_out = 32;
-  return launch_sig_to_planes(d_sig, ld_sig, n, n_hash, d_planes, ld_planes, stream);
+  return launch_sig_to_planes(d_sig, ld_sig, n, n_hash, d_planes, stream);
 }
 
 size_t da_mh_planes_workspace_bytes(int64_t n, int n_hash) { return mh_planes_workspace_bytes(n, n_hash); }
+int64_t da_mh_planes_words(int64_t n, int n_hash) { return mh_planes_words(n, n_hash); }
 
-int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work, size_t work_bytes,
-                     uint32_t *d_planes, int64_t ld_planes, int *plane_bits_out, void *stream) {
+int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, int min_plane_bits, void *d_work,
+                     size_t work_bytes, uint32_t *d_planes, int64_t planes_words, int *plane_bits_out, void *stream) {
   if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
   if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
   if (!d_sig || !d_planes || !plane_bits_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
   if (ld_sig < n_hash) return fail(DA_ERR_BAD_ARG, "ld_sig (%lld) < n_hash (%d)", (long long)ld_sig, n_hash);
-  if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
-    return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
+  if (min_plane_bits != 0 && min_plane_bits != 12 && min_plane_bits != 16 && min_plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "min_plane_bits must be 0, 12, 16 or 32 (got %d)", min_plane_bits);
+  if ((reinterpret_cast<uintptr_t>(d_planes) & 15) || planes_words < mh_planes_words(n, n_hash))
+    return fail(DA_ERR_BAD_ARG, "bit-plane buffer must be 16-byte aligned and hold da_mh_planes_words(n, n_hash) = %lld words",
+                (long long)mh_planes_words(n, n_hash));
   if (reinterpret_cast<uintptr_t>(d_work) & 255) return fail(DA_ERR_BAD_ARG, "workspace must be 256-byte aligned");
-  return build_planes(d_sig, ld_sig, n, n_hash, d_work, work_bytes, d_planes, ld_planes, plane_bits_out,
+  return build_planes(d_sig, ld_sig, n, n_hash, min_plane_bits, d_work, work_bytes, d_planes, plane_bits_out,
                       static_cast<hipStream_t>(stream));
 }
 
-int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash,
+int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, int symmetric, int kind, void *d_out,
                       int64_t ld, void *stream) {
   if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
@@ -315,10 +323,10 @@ int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int plane_bit
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "bad output kind");
   if (n_hash > 65535)
     return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
-  if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
-    return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
-  if (plane_bits != 16 && plane_bits != 32) return fail(DA_ERR_BAD_ARG, "plane_bits must be 16 or 32 (got %d)", plane_bits);
-  return launch_mh_compare(d_planes, ld_planes, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
+  if (reinterpret_cast<uintptr_t>(d_planes) & 15) return fail(DA_ERR_BAD_ARG, "bit-plane buffer must be 16-byte aligned");
+  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 16 && plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 16 or 32 (got %d)", plane_bits);
+  return launch_mh_compare(d_planes, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
                            static_cast<hipStream_t>(stream), plane_bits);
 }
 
@@ -364,7 +372,7 @@ int64_t da_shard_ld(int64_t n, int world, int is_nw) {
   return shard_geom(n, world, is_nw ? 64 : 128).W;
 }
 
-int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash, int rank,
+int da_dev_mh_compare_shard(const uint32_t *d_planes, int plane_bits, int64_t n, int n_hash, int rank,
                             int world, uint16_t *d_local, int64_t ld, void *stream) {
   if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
   if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
@@ -372,11 +380,11 @@ int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int pla
   if (!d_planes || !d_local || world <= 0 || rank < 0 || rank >= world) return fail(DA_ERR_BAD_ARG, "bad shard arguments");
   const ShardGeom sg = shard_geom(n, world, 128);
   if (ld < sg.W) return fail(DA_ERR_BAD_ARG, "ld (%lld) < da_shard_ld (%lld)", (long long)ld, (long long)sg.W);
-  if ((ld_planes & 63) || (reinterpret_cast<uintptr_t>(d_planes) & 15) || ld_planes < 2 * sig_ld_for(n_hash))
-    return fail(DA_ERR_BAD_ARG, "bit-plane matrix must be 16-byte aligned with ld_planes a multiple of 64, >= da_planes_ld(n_hash)");
-  if (plane_bits != 16 && plane_bits != 32) return fail(DA_ERR_BAD_ARG, "plane_bits must be 16 or 32 (got %d)", plane_bits);
+  if (reinterpret_cast<uintptr_t>(d_planes) & 15) return fail(DA_ERR_BAD_ARG, "bit-plane buffer must be 16-byte aligned");
+  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 16 && plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 16 or 32 (got %d)", plane_bits);
   if ((int64_t)rank * 128 >= n) return DA_OK;  // this rank owns no rows
-  return launch_mh_compare(d_planes, ld_planes, n, n_hash, (int64_t)rank * 128, n, false, DA_OUT_COMPACT, d_local, ld,
+  return launch_mh_compare(d_planes, n, n_hash, (int64_t)rank * 128, n, false, DA_OUT_COMPACT, d_local, ld,
                            static_cast<hipStream_t>(stream), plane_bits, world, true, sg.Q, sg.W);
 }
 
@@ -489,26 +497,26 @@ int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int6
   if ((rc = require_device()) != DA_OK) return rc;
   DeviceInput in;
   if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
-  const int64_t lds = sig_ld_for(n_hash), ldp = 2 * lds;
+  const int64_t lds = sig_ld_for(n_hash);
   DevBuf sig, planes, cnt, hist, keep, cnt_edges;
   if ((rc = sig.alloc((size_t)n * lds * 4)) != DA_OK) return rc;
-  if ((rc = planes.alloc((size_t)n * ldp * 4)) != DA_OK) return rc;
+  if ((rc = planes.alloc((size_t)mh_planes_words(n, n_hash) * 4)) != DA_OK) return rc;
   if ((rc = cnt.alloc((size_t)n * (size_t)n * 2)) != DA_OK) return rc;   // uint16 counts stay on the device
   const int nbins = n_hash + 1;
   if ((rc = hist.alloc((size_t)nbins * 8)) != DA_OK) return rc;
   DA_HIP_TRY(hipMemset(hist.p, 0, (size_t)nbins * 8));
   if ((rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash, in.seeds.as<uint32_t>(),
-                                      sig.as<uint32_t>(), lds, nullptr, 0, nullptr)) != DA_OK) return rc;
+                                      sig.as<uint32_t>(), lds, nullptr)) != DA_OK) return rc;
   int bits = 32;
   {
     DevBuf work;
     const size_t wb = mh_planes_workspace_bytes(n, n_hash);
     if ((rc = work.alloc(wb)) != DA_OK) return rc;
-    if ((rc = build_planes(sig.as<uint32_t>(), lds, n, n_hash, work.p, wb, planes.as<uint32_t>(), ldp, &bits, nullptr)) != DA_OK)
+    if ((rc = build_planes(sig.as<uint32_t>(), lds, n, n_hash, 0, work.p, wb, planes.as<uint32_t>(), &bits, nullptr)) != DA_OK)
       return rc;
     DA_HIP_TRY(hipStreamSynchronize(nullptr));   // the workspace is released here
   }
-  if ((rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, DA_OUT_COMPACT, cnt.p, n, nullptr, bits)) != DA_OK)
+  if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, DA_OUT_COMPACT, cnt.p, n, nullptr, bits)) != DA_OK)
     return rc;
   if ((rc = launch_upper_histogram(cnt.as<uint16_t>(), n, n, nbins, hist.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
   std::vector<uint64_t> h(nbins);
@@ -565,7 +573,6 @@ int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int6
 }
 
 int64_t da_sig_ld(int n_hash) { return sig_ld_for(n_hash); }
-int64_t da_planes_ld(int n_hash) { return 2 * sig_ld_for(n_hash); }
 
 // -------------------------------------------------------------- host entry
 
@@ -583,7 +590,7 @@ int da_minhash_signatures(const uint8_t *residues, const int64_t *offsets, int64
   DevBuf sig;
   if ((rc = sig.alloc((size_t)n * ld * sizeof(uint32_t))) != DA_OK) return rc;
   rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
-                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), ld, nullptr, 0, nullptr);
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), ld, nullptr);
   if (rc != DA_OK) return rc;
   DA_HIP_TRY(hipMemcpy2D(sig_out, (size_t)n_hash * 4, sig.p, (size_t)ld * 4, (size_t)n_hash * 4, (size_t)n,
                          hipMemcpyDeviceToHost));
@@ -606,17 +613,16 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   const int64_t lds = sig_ld_for(n_hash);
   DevBuf sig, planes;
   if ((rc = sig.alloc((size_t)n * lds * sizeof(uint32_t))) != DA_OK) return rc;
-  const int64_t ldp = 2 * lds;
-  if ((rc = planes.alloc((size_t)n * ldp * sizeof(uint32_t))) != DA_OK) return rc;
+  if ((rc = planes.alloc((size_t)mh_planes_words(n, n_hash) * sizeof(uint32_t))) != DA_OK) return rc;
   rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
-                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, nullptr, 0, nullptr);
+                                 in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, nullptr);
   if (rc != DA_OK) return rc;
   int bits = 32;
   {
     DevBuf work;
     const size_t wb = mh_planes_workspace_bytes(n, n_hash);
     if ((rc = work.alloc(wb)) != DA_OK) return rc;
-    if ((rc = build_planes(sig.as<uint32_t>(), lds, n, n_hash, work.p, wb, planes.as<uint32_t>(), ldp, &bits, nullptr)) != DA_OK)
+    if ((rc = build_planes(sig.as<uint32_t>(), lds, n, n_hash, 0, work.p, wb, planes.as<uint32_t>(), &bits, nullptr)) != DA_OK)
       return rc;
     DA_HIP_TRY(hipStreamSynchronize(nullptr));   // the workspace is released here
   }
@@ -627,14 +633,14 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   DevBuf dout;
   if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * esz)) != DA_OK) return rc;
   if (whole) {  // everything fits: compare only the upper triangle, store both halves
-    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, 0, n, true, kind, dout.p, n, nullptr, bits);
+    rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, kind, dout.p, n, nullptr, bits);
     if (rc != DA_OK) return rc;
     if ((rc = d2h_pipelined(out, dout.p, (size_t)n * (size_t)n * esz)) != DA_OK) return rc;
     return DA_OK;
   }
   for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
     const int64_t r1 = std::min(row_end, r0 + blk);
-    rc = launch_mh_compare(planes.as<uint32_t>(), ldp, n, n_hash, r0, r1, false, kind, dout.p, n, nullptr, bits);
+    rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, r0, r1, false, kind, dout.p, n, nullptr, bits);
     if (rc != DA_OK) return rc;
     if ((rc = d2h_pipelined(static_cast<char *>(out) + (size_t)(r0 - row_begin) * (size_t)n * esz, dout.p,
                             (size_t)(r1 - r0) * (size_t)n * esz)) != DA_OK) return rc;

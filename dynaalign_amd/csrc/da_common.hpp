@@ -50,25 +50,62 @@ inline ShardGeom shard_geom(int64_t n, int world, int tile) {
   return g;
 }
 
+// ---- layout of the bit-plane operand of k_mh_compare (written by dict_kernels.hip) -------------
+// The compare kernel stages, per 128-row tile and per stage (SP planes = SEGS 16-byte units per row),
+// 128 x SEGS units into LDS with wave-wide DMA instructions of 64 consecutive units.  The operand
+// is therefore stored in exactly that order -- [block of 128 rows][stage][LDS slot][unit] -- so a
+// DMA instruction reads 1 KiB of consecutive memory (8 full lines) instead of 16..21 separate row
+// pieces.  Slot order and the XOR swizzle of 64-byte slots are the kernel's LDS image:
+//   slot of tile row r: ((r>>5)*2 + (r&1))*16 + ((r&31)>>1)   (the 16 lanes of a ds_read_b128
+//   group hit consecutive slots);  unit position of logical segment s: s ^ ((slot>>2)&3) if SEGS == 4.
+// Two copies: rows (planes in order) and, `copy_words` further, columns (each plane pair swapped).
+__host__ __device__ inline int k2_slot(int r) { return (((r >> 5) * 2 + (r & 1)) << 4) + ((r & 31) >> 1); }
+__host__ __device__ inline int k2_row_of_slot(int s) { return ((s >> 5) << 5) + ((s & 15) << 1) + ((s >> 4) & 1); }
+struct PlaneGeom {
+  int pl;       // planes per group of 32 hash functions: 8, 12, 16 (dictionary codes) or 32 (raw)
+  int sp;       // planes per stage (pl, or 16 when pl = 32)
+  int segs;     // 16-byte units per row per stage
+  int nst;      // stages: groups x stages per group
+  int64_t blocks, copy_words;
+};
+__host__ __device__ inline PlaneGeom plane_geom(int64_t n, int n_hash, int pl) {
+  PlaneGeom g;
+  g.pl = pl; g.sp = pl == 32 ? 16 : pl; g.segs = g.sp / 4;
+  g.nst = ((n_hash + 31) / 32) * (pl / g.sp);
+  g.blocks = (n + 127) / 128;
+  g.copy_words = g.blocks * g.nst * 128 * g.sp;
+  return g;
+}
+// word offset (inside one copy) of the 16-byte unit holding logical segment `seg` of `row` in stage `st`
+__host__ __device__ inline int64_t plane_unit_word(const PlaneGeom &g, int64_t row, int st, int seg) {
+  const int rs = k2_slot((int)(row & 127));
+  const int xs = g.segs == 4 ? (rs >> 2) & 3 : 0;
+  return ((((row >> 7) * g.nst + st) * 128 + rs) * g.segs + (seg ^ xs)) * 4;
+}
+// uint32 words an operand buffer must hold for any plane count (the raw 32-plane layout is the largest)
+inline int64_t mh_planes_words(int64_t n, int n_hash) { return n > 0 && n_hash > 0 ? 2 * plane_geom(n, n_hash, 32).copy_words : 0; }
+
 // Kernel launchers implemented in the .hip translation units.  All are
 // asynchronous on `stream`; argument checking is done by the C-ABI layer.
 int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n,
                               int k, int n_hash, const uint32_t *d_seeds, uint32_t *d_sig,
-                              int64_t ld_sig, uint32_t *d_planes, int64_t ld_planes,
-                              hipStream_t stream);
-int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
+                              int64_t ld_sig, hipStream_t stream);
+int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
                       void *d_out, int64_t ld, hipStream_t stream, int plane_bits = 32, int tile_stride = 1,
                       bool upper_only = false, int fold_q = 0, int64_t fold_w = 0);
-// dict_kernels.hip: signatures -> compare operand.  Dictionary codes (16 planes per group) are exact
-// for n <= DA_DICT_MAX_N; *d_status_out points into the workspace (0 = ok) and is valid once the
-// stream has drained.
+// dict_kernels.hip: signatures -> compare operand.  Dictionary codes (8 / 12 / 16 planes per group,
+// whatever the largest column dictionary needs) are exact for n <= DA_DICT_MAX_N; *d_status_out
+// points at two ints in the workspace ({error, largest id count}), valid once the stream has drained.
 constexpr int64_t DA_DICT_MAX_N = 131068;
 size_t mh_planes_workspace_bytes(int64_t n, int n_hash);
-int launch_mh_dictionary_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work,
-                                uint32_t *d_planes, int64_t ld_planes, int **d_status_out, hipStream_t stream);
+int launch_mh_dictionary(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work,
+                         int **d_status_out, hipStream_t stream);
+int mh_plane_bits_for(int max_ids);
+int launch_ids_to_planes(const void *d_work, int64_t n, int n_hash, int plane_bits, uint32_t *d_planes,
+                         hipStream_t stream);
 int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, uint32_t *d_planes,
-                         int64_t ld_planes, hipStream_t stream);
+                         hipStream_t stream);
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
                             double *d_out, int64_t ld, hipStream_t stream);
 int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,

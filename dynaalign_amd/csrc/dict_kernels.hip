@@ -14,9 +14,10 @@
 //
 //   k_sig_transpose : sig[n][ld] -> sigT[n_hash][ldT]          (coalesced column access)
 //   k_dictionary    : one workgroup per hash function; LDS hash table over key partitions
-//   k_ids_to_planes : ids[n_hash][ldT] (uint16) -> bit planes, 16 words per 32-hash group,
-//                     row copy + pair-swapped column copy (layout of k_mh_compare<.., 16>)
-//   k_sig_to_planes : raw 32-plane layout from sig (n > DA_DICT_MAX_N, or dictionary overflow)
+//   k_ids_to_planes : ids[n_hash][ldT] (uint16) -> bit planes, 8 / 12 / 16 per 32-hash group (as
+//                     many as the largest column dictionary needs), row copy + pair-swapped column
+//                     copy, in the blocked order k_mh_compare stages them in (da_common.hpp)
+//   k_sig_to_planes : raw 32-plane operand from sig (n > DA_DICT_MAX_N, or dictionary overflow)
 #include "da_common.hpp"
 
 namespace da {
@@ -58,7 +59,8 @@ __device__ __forceinline__ int dk_part(uint32_t z, int R) { return (int)__umulhi
 __device__ __forceinline__ uint32_t dk_slot(uint32_t z) { return (z * 0x9e3779b1u) >> (32 - 14); }
 static_assert(DK_SLOTS == (1 << 14), "dk_slot assumes 2^14 slots");
 
-// status word: 0 ok, 1 a partition overflowed its table, 2 more than 65534 repeated values
+// status[0]: 0 ok, 1 a partition overflowed its table, 2 more than 65534 repeated values
+// status[1]: the largest number of repeated values (= ids handed out) in any column
 __global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__restrict__ sigT, int64_t ldT, int64_t n,
                                                            int R, uint16_t *__restrict__ idsT, int64_t ld_ids,
                                                            int *__restrict__ status) {
@@ -158,19 +160,21 @@ __global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__res
   }
   if (overflow) atomicMax(status, 1);
   if (tid == 0 && base > 65534u) atomicMax(status, 2);
+  if (tid == 0) atomicMax(status + 1, (int)base);
 }
 
 // ----------------------------------------------------------- bit planes --
 // 64 sequences x all hash functions per workgroup.  Per chunk of 64 hash functions the 64 x 64
 // uint16 code tile is staged in LDS; a wave then owns a sequence and its lane l holds the code of
 // hash function h0 + l, so one 64-bit ballot per bit is plane p of two adjacent 32-hash groups.
-// Singletons (0xFFFF): row copy gets 0xFFFE, column copy 0xFFFF -- they differ in plane 0 only.
+// pl = planes kept per group (8, 12 or 16: every id is < 2^pl - 2).  Singletons (0xFFFF in idsT):
+// row copy gets 2^pl - 2, column copy 2^pl - 1 -- they differ in plane 0 only.
 __global__ __launch_bounds__(256) void k_ids_to_planes(const uint16_t *__restrict__ idsT, int64_t ld_ids, int64_t n,
-                                                       int n_hash, uint32_t *__restrict__ planes, int64_t ld_planes) {
+                                                       int n_hash, int pl, uint32_t *__restrict__ planes) {
   __shared__ uint16_t tile[64][66];
   const int64_t i0 = (int64_t)blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half_ld = (int)(ld_planes >> 1);
+  const PlaneGeom pg = plane_geom(n, n_hash, pl);
   const int ngroup = (n_hash + 31) / 32;
   for (int h0 = 0; h0 < ngroup * 32; h0 += 64) {
     __syncthreads();
@@ -185,40 +189,39 @@ __global__ __launch_bounds__(256) void k_ids_to_planes(const uint16_t *__restric
       if (i >= n) break;                         // wave-uniform
       const uint32_t v = tile[lane][sq];
       const bool single = (v == 0xFFFFu) && (h0 + lane < n_hash);
-      const uint32_t va = single ? 0xFFFEu : v;
+      const uint32_t va = single ? (1u << pl) - 2u : v;
+      const uint32_t vb = single ? (1u << pl) - 1u : v;
       uint32_t wa = 0, wb = 0;
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
+      for (int p = 0; p < pl; ++p) {                       // pl is uniform
         const unsigned long long m = __ballot((va >> p) & 1u);
         const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
         wa = ((lane & 31) == p) ? half : wa;
       }
       {
-        const unsigned long long m = __ballot(v & 1u);     // plane 0 of the column copy
+        const unsigned long long m = __ballot(vb & 1u);    // plane 0 of the column copy
         const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
         wb = ((lane & 31) == 0) ? half : wa;
       }
-      const int g = (h0 >> 5) + (lane >> 5);
+      const int g = (h0 >> 5) + (lane >> 5);               // the group is the stage (pl <= 16)
       const int p = lane & 31;
-      if (p < 16 && g < ngroup) {
-        uint32_t *prow = planes + i * ld_planes;
-        prow[g * 16 + p] = wa;
-        prow[half_ld + g * 16 + (p ^ 1)] = wb;     // pair-swapped copy (see k_mh_compare)
+      if (p < pl && g < ngroup) {
+        const int64_t w = plane_unit_word(pg, i, g, p >> 2);
+        planes[w + (p & 3)] = wa;
+        planes[pg.copy_words + w + ((p & 3) ^ 1)] = wb;    // pair-swapped copy (see k_mh_compare)
       }
     }
   }
 }
 
-// raw values, 32 planes per group: the layout k_minhash_signatures also writes
+// raw values, 32 planes per group = two 16-plane stages
 __global__ __launch_bounds__(256) void k_sig_to_planes(const uint32_t *__restrict__ sig, int64_t ld_sig, int64_t n,
-                                                       int n_hash, uint32_t *__restrict__ planes, int64_t ld_planes) {
+                                                       int n_hash, uint32_t *__restrict__ planes) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= n) return;
-  const int half_ld = (int)(ld_planes >> 1);
+  const PlaneGeom pg = plane_geom(n, n_hash, 32);
   const int ngroup = (n_hash + 31) / 32;
   const uint32_t *row = sig + i * ld_sig;
-  uint32_t *prow = planes + i * ld_planes;
   for (int h0 = 0; h0 < ngroup * 32; h0 += 64) {
     const int h = h0 + lane;
     const uint32_t v = (h < n_hash) ? row[h] : 0u;
@@ -229,9 +232,12 @@ __global__ __launch_bounds__(256) void k_sig_to_planes(const uint32_t *__restric
       const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
       w = ((lane & 31) == p) ? half : w;
     }
-    if (h < ngroup * 32) {
-      prow[h] = w;
-      prow[half_ld + (h ^ 1)] = w;
+    const int g = (h0 >> 5) + (lane >> 5);
+    const int p = lane & 31;
+    if (g < ngroup) {
+      const int64_t u = plane_unit_word(pg, i, 2 * g + (p >> 4), (p & 15) >> 2);
+      planes[u + (p & 3)] = w;
+      planes[pg.copy_words + u + ((p & 3) ^ 1)] = w;
     }
   }
 }
@@ -246,31 +252,49 @@ size_t mh_planes_workspace_bytes(int64_t n, int n_hash) {
   return (size_t)n_hash * ldT * 4 + (size_t)n_hash * ldT * 2 + 256;
 }
 
-// d_status (inside the workspace) is left for the caller to read after the stream has drained
-int launch_mh_dictionary_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work,
-                                uint32_t *d_planes, int64_t ld_planes, int **d_status_out, hipStream_t stream) {
+// Step 1 (transpose + dictionary): leaves the codes and two status words in the workspace.
+// *d_status_out points at them; read them once the stream has drained, pick the plane count
+// (mh_plane_bits_for) and run step 2.
+int launch_mh_dictionary(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work,
+                         int **d_status_out, hipStream_t stream) {
   const int64_t ldT = dict_ldT(n);
   uint32_t *sigT = static_cast<uint32_t *>(d_work);
   uint16_t *idsT = reinterpret_cast<uint16_t *>(sigT + (size_t)n_hash * ldT);
   int *status = reinterpret_cast<int *>(reinterpret_cast<char *>(d_work) + (size_t)n_hash * ldT * 6);
   status = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(status) + 63) & ~(uintptr_t)63);
   *d_status_out = status;
-  DA_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream));
+  DA_HIP_TRY(hipMemsetAsync(status, 0, 2 * sizeof(int), stream));
   hipLaunchKernelGGL(k_sig_transpose, dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_hash, 64)), dim3(256), 0,
                      stream, d_sig, ld_sig, n, n_hash, sigT, ldT);
   int R = (int)ceil_div(n, DK_PART_KEYS);
   if (R < 2) R = 2;
   hipLaunchKernelGGL(k_dictionary, dim3((unsigned)n_hash), dim3(DK_THREADS), 0, stream, sigT, ldT, n, R, idsT, ldT, status);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+// planes per group that hold `max_ids` dense ids plus the two singleton codes
+int mh_plane_bits_for(int max_ids) {
+  if (max_ids + 2 <= (1 << 8)) return 8;
+  if (max_ids + 2 <= (1 << 12)) return 12;
+  return 16;
+}
+
+// Step 2: codes -> bit planes, `plane_bits` (8 / 12 / 16) planes per group of 32 hash functions
+int launch_ids_to_planes(const void *d_work, int64_t n, int n_hash, int plane_bits, uint32_t *d_planes,
+                         hipStream_t stream) {
+  const int64_t ldT = dict_ldT(n);
+  const uint16_t *idsT = reinterpret_cast<const uint16_t *>(static_cast<const uint32_t *>(d_work) + (size_t)n_hash * ldT);
   hipLaunchKernelGGL(k_ids_to_planes, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, stream, idsT, ldT, n, n_hash,
-                     d_planes, ld_planes);
+                     plane_bits, d_planes);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
 
 int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, uint32_t *d_planes,
-                         int64_t ld_planes, hipStream_t stream) {
+                         hipStream_t stream) {
   hipLaunchKernelGGL(k_sig_to_planes, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, d_sig, ld_sig, n, n_hash,
-                     d_planes, ld_planes);
+                     d_planes);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

@@ -9,6 +9,8 @@
 // work; no MFMA (an equality count is not a contraction).
 #include "da_common.hpp"
 
+#include <type_traits>
+
 namespace da {
 namespace {
 
@@ -59,8 +61,7 @@ constexpr int K1_CHUNK = 1024;  // window positions staged per pass
 template <bool K_IS_4>
 __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
     const uint8_t *__restrict__ residues, const int64_t *__restrict__ offsets, int k, int n_hash,
-    const uint32_t *__restrict__ seeds, uint32_t *__restrict__ sig, int64_t ld_sig,
-    uint32_t *__restrict__ planes, int64_t ld_planes) {
+    const uint32_t *__restrict__ seeds, uint32_t *__restrict__ sig, int64_t ld_sig) {
   extern __shared__ uint32_t lds_k1[];
   const int64_t seq = blockIdx.x;
   const int64_t beg = offsets[seq];
@@ -115,37 +116,6 @@ __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
       row[h] = best;
     }
   }
-
-  // ---- bit-plane copy for the compare kernel: every group of 32 hash functions
-  // g is stored as 32 words, word p holding bit p of sig[32g+0..31] (a 32x32 bit
-  // transpose done with wave ballots: lane l of a wave holds h = base + l, so the
-  // low/high halves of a 64-bit ballot are plane p of two adjacent groups).
-  // Hash functions >= n_hash contribute 0 bits in every sequence, i.e. "equal".
-  if (planes) {
-    uint32_t *prow = planes + seq * ld_planes;
-    const int lane = threadIdx.x & 63;
-    const int half_ld = (int)(ld_planes >> 1);       // words per copy (multiple of 32)
-    for (int h0 = 0; h0 < half_ld; h0 += K1_THREADS) {
-      const int hw = h0 + (threadIdx.x & ~63);       // first h of this wave
-      if (hw >= half_ld) break;                      // wave-uniform
-      const int h = hw + lane;
-      const uint32_t v = (h < n_hash) ? row[h] : 0u;  // own earlier store (same thread wrote row[h])
-      uint32_t w = 0;
-#pragma unroll
-      for (int p = 0; p < 32; ++p) {
-        const unsigned long long m = __ballot((v >> p) & 1u);
-        const uint32_t half = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
-        w = ((lane & 31) == p) ? half : w;
-      }
-      // Second copy with each pair of planes swapped (word h^1), stored ld_planes/2 words
-      // further: the compare kernel reads its column operand from it so that the two
-      // plane registers of every v_bitop3 differ in VGPR-index parity (see k_mh_compare).
-      if (h < half_ld) {
-        prow[h] = w;
-        prow[half_ld + (h ^ 1)] = w;
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------- compare --
@@ -169,22 +139,17 @@ __global__ __launch_bounds__(K1_THREADS) void k_minhash_signatures(
 // staged through LDS per step.
 constexpr int K2_TILE = 128;
 constexpr int K2_GROUP = 32;         // hash functions per bit-plane group (= planes per group)
-constexpr int K2_SP = 16;            // planes per LDS stage (half a group)
-constexpr int K2_SEGS = K2_SP / 4;   // 16-byte segments per row per stage
+// planes per LDS stage and 16-byte segments per row per stage depend on the plane count PL of the
+// kernel instance: PL = 32 -> 16 planes (half a group), PL = 16 / 12 / 8 -> the whole group
 constexpr int K2_NSTAGE = 3;         // LDS ring depth
 constexpr int K2_BAND = 8;           // tile rows per L2-resident band
 constexpr int K2_THREADS = 256;
 
 // Rows/cols owned by lane coordinate t (0..15):  32*g + 2*t + e, g=0..3, e=0..1.
-// LDS slot of tile row r:  ((r>>5)*2 + (r&1))*16 + ((r&31)>>1)  -- makes the
-// 16 lanes of a ds_read_b128 group hit consecutive slots.
-__device__ __forceinline__ int k2_slot(int r) { return (((r >> 5) * 2 + (r & 1)) << 4) + ((r & 31) >> 1); }
-// Inverse: which tile row lives in LDS slot s.
-__device__ __forceinline__ int k2_row_of_slot(int s) { return ((s >> 5) << 5) + ((s & 15) << 1) + ((s >> 4) & 1); }
-// 16-byte unit index inside one operand buffer (4 segments per slot per stage).
-// The XOR swizzle makes a ds_read_b128 group (<= 8 consecutive slots, one
-// segment) hit 8 different 16-byte bank groups.
-__device__ __forceinline__ int k2_unit(int slot, int seg) { return slot * K2_SEGS + (seg ^ ((slot >> 2) & 3)); }
+// LDS slot order (k2_slot / k2_row_of_slot) and the operand's memory layout: da_common.hpp.
+// A ds_read_b128 of the compute loop touches <= 8 consecutive slots at one segment.  With 2 or 3
+// segments per slot (32- / 48-byte slots) those land in 8 different 16-byte bank groups by
+// themselves; with 4 (64-byte slots) the segment index is XOR-swizzled with (slot >> 2) & 3.
 
 // d | (a ^ b) as ONE full-rate v_bitop3_b32 (truth table over S0=0xF0,S1=0xCC,S2=0xAA:
 // 0xF0 | (0xCC ^ 0xAA) = 0xF6).  Left to itself hipcc picks v_xor + v_or3 (half rate).
@@ -200,6 +165,15 @@ struct TileId { int ti, tj; bool valid; };
 // b-tiles.  Consecutive ids go to one XCD (the caller's blockIdx remap).
 //   symmetric: only tiles with tj >= ti.   T = tiles per side (columns),
 //   rect     : tile rows [0,TR) x tile cols [0,T).
+// Everything here is wave-uniform and runs while the other workgroups of the CU are in their
+// plane loops, so it is written to stay cheap: 32-bit integers, float estimates corrected by
+// exact integer tests, no 64-bit division, no double sqrt.  Needs ntiles < 2^31, T < 2^20.
+__device__ __forceinline__ int div_small(int l, int h) {   // l / h for 0 <= l < 2^24, 1 <= h <= 8
+  int q = (int)__fdividef((float)l, (float)h);
+  while (q * h > l) --q;
+  while ((q + 1) * h <= l) ++q;
+  return q;
+}
 __device__ __forceinline__ TileId decode_tile(int64_t L, int TR, int T, bool symmetric) {
   TileId o{0, 0, true};
   const int S = K2_BAND;
@@ -217,14 +191,14 @@ __device__ __forceinline__ TileId decode_tile(int64_t L, int TR, int T, bool sym
   }
   // full bands: count(B) = c0 - S*S*B, c0 = S(S+1)/2 + (T-S)*S ; prefix(B) = B*c0 - S*S*B(B-1)/2
   const int nfull = T / S;  // bands with S rows
-  const int64_t c0 = (int64_t)S * (S + 1) / 2 + (int64_t)(T - S) * S;
-  auto prefix = [&](int64_t B) { return B * c0 - (int64_t)S * S * (B * (B - 1) / 2); };
-  int64_t B;
+  const int c0 = S * (S + 1) / 2 + (T - S) * S;
+  auto prefix = [&](int B) { return (int64_t)B * c0 - (int64_t)(S * S / 2) * B * (B - 1); };
+  int B;
   if (nfull > 0 && L < prefix(nfull)) {
-    // solve prefix(B) <= L: (S*S/2) B^2 - (c0 + S*S/2) B + L >= 0
-    const double a = 0.5 * S * S, b = (double)c0 + a;
-    double disc = b * b - 4.0 * a * (double)L;
-    B = (int64_t)((b - sqrt(disc > 0 ? disc : 0)) / (2.0 * a));
+    // solve prefix(B) <= L: (S*S/2) B^2 - (c0 + S*S/2) B + L >= 0 -- float estimate, exact correction
+    const float a = 0.5f * S * S, b = (float)c0 + a;
+    const float disc = b * b - 4.0f * a * (float)L;
+    B = (int)((b - sqrtf(disc > 0.0f ? disc : 0.0f)) / (2.0f * a));
     if (B < 0) B = 0;
     if (B > nfull - 1) B = nfull - 1;
     while (B > 0 && prefix(B) > L) --B;
@@ -232,21 +206,21 @@ __device__ __forceinline__ TileId decode_tile(int64_t L, int TR, int T, bool sym
   } else {
     B = nfull;  // the partial last band (or invalid)
   }
-  const int r0 = (int)B * S;
+  const int r0 = B * S;
   const int h = (T - r0 < S) ? (T - r0) : S;
   if (h <= 0) { o.valid = false; return o; }
-  int64_t l = L - prefix(B < nfull ? B : nfull);
-  const int64_t tri = (int64_t)h * (h + 1) / 2;
+  int l = (int)(L - prefix(B < nfull ? B : nfull));   // < S * T
+  const int tri = h * (h + 1) / 2;
   if (l < tri) {  // the diagonal super-tile: column q holds q+1 tiles
     int q = 0;
-    while ((int64_t)(q + 1) * (q + 2) / 2 <= l) ++q;
+    while ((q + 1) * (q + 2) / 2 <= l) ++q;
     o.tj = r0 + q;
-    o.ti = r0 + (int)(l - (int64_t)q * (q + 1) / 2);
+    o.ti = r0 + (l - q * (q + 1) / 2);
   } else {
     l -= tri;
-    int64_t cq = l / h;
-    o.tj = r0 + h + (int)cq;
-    o.ti = r0 + (int)(l - cq * h);
+    const int cq = div_small(l, h);
+    o.tj = r0 + h + cq;
+    o.ti = r0 + (l - cq * h);
   }
   o.valid = o.tj < T;
   return o;
@@ -257,21 +231,38 @@ __host__ __device__ inline int64_t count_tiles(int TR, int T, bool symmetric) {
   return (int64_t)T * (T + 1) / 2;
 }
 
+// Phase stamps for tools/k2_timeline.py; only in a -DDA_K2_TIMING build (never the shipped library).
+#ifdef DA_K2_TIMING
+__device__ unsigned long long *g_k2_timing = nullptr;   // [blocks][8]: t_entry, t_loop, t_loop_end, t_exit, hw_id, xcc_id
+#define K2_STAMP(i) do { if (g_k2_timing && threadIdx.x == 0) g_k2_timing[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define K2_STAMP_HW() do { if (g_k2_timing && threadIdx.x == 0) { \
+    unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+    g_k2_timing[(size_t)blockIdx.x * 8 + 4] = hw; g_k2_timing[(size_t)blockIdx.x * 8 + 5] = xcc; } } while (0)
+#else
+#define K2_STAMP(i) do { } while (0)
+#define K2_STAMP_HW() do { } while (0)
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-// PL = bit planes per group of 32 hash functions: 32 (raw uint32 values) or 16 (dictionary codes of
-// dict_kernels.hip: same equalities off the diagonal, half the planes; the diagonal is forced).
+// PL = bit planes per group of 32 hash functions: 32 (raw uint32 values) or 16 / 12 / 8 (dictionary
+// codes of dict_kernels.hip, as many planes as the largest column dictionary needs: same equalities
+// off the diagonal, a fraction of the planes; the diagonal is forced).
 template <bool SYM, bool F64, int PL>
 __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
-    const uint32_t *__restrict__ planes, int64_t ld_p, int64_t n, int n_hash, int64_t row_begin,
+    const uint32_t *__restrict__ planes, int64_t n, int n_hash, int64_t row_begin,
     int64_t row_end, int tile_stride, int upper_only, int TR, void *__restrict__ out_v, int64_t ld,
     int64_t ntiles, int64_t per_xcd, int fold_q, int64_t fold_w, int band) {
   // Row-block geometry: local tile row q covers global rows row_begin + q*tile_stride*128 + [0,128)
   // (tile_stride = 1: a contiguous block; = world: the cyclic shard of one rank) and is stored at
   // local rows q*128 + [0,128) of `out`.  upper_only skips tiles left of the diagonal.
-  // ring of 3 stages; a stage = 16 planes of {128 a-rows, 128 b-rows} = 256 x 64 B = 16 KiB
-  constexpr int STAGE_UNITS = 2 * K2_TILE * K2_SEGS;
+  // ring of 3 stages; a stage = SP planes of {128 a-rows, 128 b-rows} = 256 x 4*SP B (16 KiB at SP = 16)
+  constexpr int SP = (PL == 32) ? 16 : PL;       // planes per stage
+  constexpr int SEGS = SP / 4;                   // 16-byte segments per row per stage
+  constexpr int SPG = PL / SP;                   // stages per group: 2 (PL = 32) or 1
+  constexpr int STAGE_UNITS = 2 * K2_TILE * SEGS;
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[K2_NSTAGE * STAGE_UNITS];
 
   // ---- which tile.  Blocks b and b+8 share an XCD (speed only).
@@ -280,6 +271,8 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   //   row block: bands of 8 tile rows are dealt round-robin to the XCDs -- with upper_only the
   //              valid part of a band shrinks with its row index, and contiguous ranges would
   //              leave the last XCDs idle (measured: 1.7x slower).
+  K2_STAMP(0);
+  K2_STAMP_HW();
   const int64_t bid = blockIdx.x;
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
   TileId tid2;
@@ -288,14 +281,15 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     if (L >= ntiles) return;
     tid2 = decode_tile(L, TR, T, true);
   } else {
-    const int64_t per_band = (int64_t)band * T;                           // band = tile rows per band (launcher's choice)
-    const int64_t k = bid >> 3;
-    const int r0 = ((int)(bid & 7) + 8 * (int)(k / per_band)) * band;     // first local tile row of the band
-    const int64_t l = k % per_band;
+    const uint32_t per_band = (uint32_t)band * (uint32_t)T;               // band = tile rows per band (launcher's choice)
+    const uint32_t k = (uint32_t)(bid >> 3);
+    const uint32_t kb = k / per_band;
+    const int r0 = ((int)(bid & 7) + 8 * (int)kb) * band;                 // first local tile row of the band
+    const int l = (int)(k - kb * per_band);
     const int h = (TR - r0 < band) ? (TR - r0) : band;
     if (h <= 0) return;
-    tid2.tj = (int)(l / h);
-    tid2.ti = r0 + (int)(l - (int64_t)tid2.tj * h);
+    tid2.tj = div_small(l, h);
+    tid2.ti = r0 + (l - tid2.tj * h);
     tid2.valid = tid2.tj < T;
   }
   if (!tid2.valid) return;
@@ -318,42 +312,47 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   const int ty = ((wave >> 1) << 3) + (lane >> 3); // row coordinate 0..15
 
   // ---- staging by LDS-DMA (global_load_lds_dwordx4): one wave instruction
-  // lands 64 x 16 B = 16 slots x 64 B contiguously in LDS -- no VGPRs, no
-  // ds_write.  LDS is written linearly (base + lane*16), so the XOR swizzle is
-  // applied on the SOURCE side: lane l of instruction q fills physical
-  // position (l & 3) of slot (q*16 + l>>2) with logical segment
-  // (l&3) ^ ((slot>>2)&3).  A wave issues 4 instructions per stage.
-  const uint32_t *src[4];
+  // lands 64 x 16 B contiguously in LDS -- no VGPRs, no ds_write.  LDS is
+  // written linearly (base + lane*16): 16-byte unit u of a stage is physical
+  // position u % SEGS of slot u / SEGS.  The operand is stored in that very
+  // order per 128-row block (plane_unit_word), so for a tile aligned to 128 rows
+  // the 64 lanes of an instruction read 1 KiB of consecutive memory; an unaligned
+  // row block (arbitrary row_begin) just gathers.  A wave issues SEGS instructions per stage.
+  const PlaneGeom pg = plane_geom(n, n_hash, PL);
+  const uint32_t *src[SEGS];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int s = (wave * 4 + q) * 16 + (lane >> 2);  // slot 0..255 (a: 0..127, b: 128..255)
+  for (int q = 0; q < SEGS; ++q) {
+    const int u = (wave * SEGS + q) * 64 + lane;
+    const int s = u / SEGS;                           // slot 0..255 (a: 0..127, b: 128..255)
     const int sl = s & 127;
-    const int seg = (lane & 3) ^ ((sl >> 2) & 3);
+    const int seg = (u - s * SEGS) ^ (SEGS == 4 ? ((sl >> 2) & 3) : 0);   // logical segment wanted at this position
     int64_t g = ((s < 128) ? I0 : J0) + k2_row_of_slot(sl);
     if (g > n - 1) g = n - 1;                          // rows past the end: any valid row, never stored
     // row operand (a) from the plain copy, column operand (b) from the pair-swapped copy
-    src[q] = planes + g * ld_p + ((s < 128) ? 0 : (ld_p >> 1)) + seg * 4;
+    src[q] = planes + ((s < 128) ? 0 : pg.copy_words) + plane_unit_word(pg, g, 0, seg);
   }
   // The DMA is issued from inline asm on purpose: with the builtin, hipcc must assume the LDS write may
   // alias the ring slots being read and puts s_waitcnt vmcnt(0) in front of the first ds_read of every
   // segment, which drains the "asynchronous" copy at every stage (seen in the ISA).  Hidden in asm the
   // copies stay in flight; the counted waits below (wait_stage) are then OUR responsibility:
-  // each wave issues exactly 4 VMEM operations per stage and nothing else touches vmcnt in the loop.
+  // each wave issues exactly SEGS VMEM operations per stage and nothing else touches vmcnt in the loop.
   const uint32_t lds_wave_base =
-      __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)(lds_ab + wave * 4 * 64));
-  auto issue = [&](int stage) {  // stage s holds planes [16 s, 16 s + 16)
+      __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)(lds_ab + wave * SEGS * 64));
+  auto issue = [&](int stage) {  // stage s of a block: 128 * SP words further
     const uint32_t base = lds_wave_base + (uint32_t)(stage % K2_NSTAGE) * (uint32_t)(STAGE_UNITS * sizeof(uint4));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t *g = src[q] + stage * K2_SP;
+    for (int q = 0; q < SEGS; ++q) {
+      const uint32_t *g = src[q] + stage * (128 * SP);
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                    :: "v"(g), "s"(base + (uint32_t)(q * 64 * sizeof(uint4))) : "memory", "m0");
     }
   };
-  // before the barrier that opens stage s: its 4 copies must have landed; the 4 of stage s+1 may still fly
+  // before the barrier that opens stage s: its SEGS copies must have landed; those of stage s+1 may still fly
   auto wait_stage = [&](bool younger_in_flight) {
-    if (younger_in_flight) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (SEGS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (SEGS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
 
   uint32_t mis[8][4];  // mismatch counters, two 16-bit counters per register (columns 2j, 2j+1)
@@ -364,80 +363,109 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
 
   // lane-constant parts of the LDS read addresses (16-byte units); the r / c
   // strides (16 slots = 64 units) fold into the ds_read immediate offset.
-  const int base_a = ty * K2_SEGS, base_b = K2_TILE * K2_SEGS + tx * K2_SEGS;
-  const int xa = (ty >> 2) & 3, xb = (tx >> 2) & 3;  // (slot >> 2) & 3 of the lane's slots
+  const int base_a = ty * SEGS, base_b = K2_TILE * SEGS + tx * SEGS;
+  const int xa = SEGS == 4 ? (ty >> 2) & 3 : 0, xb = SEGS == 4 ? (tx >> 2) & 3 : 0;  // (slot >> 2) & 3 of the lane's slots
 
-  uint32_t d[8][8];  // d |= a_p ^ b_p over the 32 planes of a group
+  uint32_t d[8][8];  // d |= a_p ^ b_p over the planes of a group
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
     for (int c = 0; c < 8; ++c) d[r][c] = 0;
-  auto compute = [&](int stage) {
+  // Operands of the 4-plane segment about to be computed.  A stage is walked segment by segment;
+  // the row operands of segment s+1 are fetched into a[r] right after a[r]'s last use in segment s
+  // (column 7), and the first operands of a stage right after its barrier, BEFORE the popcounts of
+  // the previous group -- so a wave meets an LDS round trip with VALU work in hand instead of idle.
+  uint4 a[8], b;
+  auto preload = [&](int stage) __attribute__((always_inline)) {
     const uint4 *S = lds_ab + (stage % K2_NSTAGE) * STAGE_UNITS;
-#pragma unroll 1
-    for (int seg = 0; seg < K2_SEGS; ++seg) {  // 4 planes per 16-byte segment
-      const uint4 *Sa = S + base_a + (seg ^ xa);
-      const uint4 *Sb = S + base_b + (seg ^ xb);
-      // first column operand first, then the 8 row operands: LDS returns in order, so the first
-      // v_bitop3 can start after two reads instead of nine (the compiler emits counted lgkmcnt waits)
-      uint4 b = Sb[0];
-      uint4 a[8];
+    b = S[base_b + xb];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) a[r] = Sa[r * 16 * K2_SEGS];
+    for (int r = 0; r < 8; ++r) a[r] = S[base_a + xa + r * 16 * SEGS];
+  };
+  // init: first segment of a group -- d = a ^ b (v_xor, full rate) instead of d |= a ^ b, which saves
+  // clearing the 64 accumulators after every popcount
+  auto segment = [&](const uint4 *S, int seg, auto more_tag, auto init_tag) __attribute__((always_inline)) {
+    constexpr bool more = decltype(more_tag)::value;               // another segment of this stage follows
+    constexpr bool init = decltype(init_tag)::value;
+    const uint4 *Sb = S + base_b + (seg ^ xb);
+    const uint4 *nSa = S + base_a + ((seg + 1) ^ xa);
+    const uint4 *nSb = S + base_b + ((seg + 1) ^ xb);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const uint4 bn = (c + 1 < 8) ? Sb[(c + 1) * 16 * K2_SEGS] : b;   // next column's operand in flight
+    for (int c = 0; c < 8; ++c) {
+      uint4 bn = b;                                                // next column's operand in flight
+      if (c + 1 < 8) bn = Sb[(c + 1) * 16 * SEGS];
+      else if (more) { bn = nSb[0]; __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          // b holds planes (1,0,3,2): plane p sits in registers of opposite index parity in
-          // a and b, so no v_bitop3 has all three sources in one VGPR bank (half rate otherwise)
-          uint32_t v = or_xor(d[r][c], a[r].x, b.y);
-          v = or_xor(v, a[r].y, b.x);
-          v = or_xor(v, a[r].z, b.w);
-          d[r][c] = or_xor(v, a[r].w, b.z);
+      for (int r = 0; r < 8; ++r) {
+        // b holds planes (1,0,3,2): plane p sits in registers of opposite index parity in
+        // a and b, so no v_bitop3 has all three sources in one VGPR bank (half rate otherwise)
+        uint32_t v = init ? (a[r].x ^ b.y) : or_xor(d[r][c], a[r].x, b.y);
+        v = or_xor(v, a[r].y, b.x);
+        v = or_xor(v, a[r].z, b.w);
+        d[r][c] = or_xor(v, a[r].w, b.z);
+        if (c == 7 && more) {
+          // last column: rows strictly one after the other (a wave issues one VALU op per 4 cycles, so the
+          // dependent chain costs nothing) and each row operand is re-fetched the moment it is dead --
+          // left alone the scheduler interleaves the 8 chains and all 8 reads land in the last 8 ops
+          a[r] = nSa[r * 16 * SEGS];
+          __builtin_amdgcn_sched_barrier(0);
         }
-        b = bn;
       }
+      b = bn;
+    }
+  };
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    const uint4 *S = lds_ab + (stage % K2_NSTAGE) * STAGE_UNITS;
+    if (SPG == 1) {   // the stage is a whole group: first segment initialises d
+      if (SEGS > 1) segment(S, 0, std::true_type{}, std::true_type{});
+      else segment(S, 0, std::false_type{}, std::true_type{});
+#pragma unroll 1
+      for (int seg = 1; seg < SEGS - 1; ++seg) segment(S, seg, std::true_type{}, std::false_type{});
+      if (SEGS > 1) segment(S, SEGS - 1, std::false_type{}, std::false_type{});
+    } else {
+#pragma unroll 1
+      for (int seg = 0; seg < SEGS - 1; ++seg) segment(S, seg, std::true_type{}, std::false_type{});
+      segment(S, SEGS - 1, std::false_type{}, std::false_type{});
     }
   };
 
   const int ngroup = (n_hash + K2_GROUP - 1) / K2_GROUP;
-  const int nstage = (PL / K2_SP) * ngroup;
-  auto count_group = [&]() {
+  const int nstage = SPG * ngroup;
+  auto count_group = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         mis[r][c] += (uint32_t)__builtin_popcount(d[r][2 * c]) + ((uint32_t)__builtin_popcount(d[r][2 * c + 1]) << 16);
+    if (SPG != 1) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+      for (int r = 0; r < 8; ++r)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) d[r][c] = 0;
+        for (int c = 0; c < 8; ++c) d[r][c] = 0;
+    }
   };
   // wait_stage: this wave's copies for the stage have landed; the barrier: so have everyone's, and
   // nobody still reads the ring slot the next issue() overwrites (it was consumed two stages ago).
+  K2_STAMP(1);
   issue(0);
   if (nstage > 1) issue(1);
-  if (PL == 32) {
-    for (int g = 0; g < ngroup; ++g) {
-      wait_stage(true);                       // stage 2g+1 was issued after stage 2g
-      __syncthreads();
-      if (2 * g + 2 < nstage) issue(2 * g + 2);
-      compute(2 * g);
-      wait_stage(2 * g + 2 < nstage);         // stage 2g+2 (if any) is younger than stage 2g+1
-      __syncthreads();
-      if (2 * g + 3 < nstage) issue(2 * g + 3);
-      compute(2 * g + 1);
-      count_group();
-    }
-  } else {
-    for (int g = 0; g < ngroup; ++g) {        // one 16-plane stage per group
-      wait_stage(g + 1 < nstage);
-      __syncthreads();
-      if (g + 2 < nstage) issue(g + 2);
-      compute(g);
-      count_group();
-    }
+  for (int st = 0; st < nstage; ++st) {
+#if defined(DA_K2_EXP_NODMA)      // timing experiments only (wrong results): what do the copies / the barrier cost?
+    if (st < 2) { wait_stage(st + 1 < nstage); __syncthreads(); }
+#elif defined(DA_K2_EXP_NOBARRIER)
+    wait_stage(st + 1 < nstage);
+    if (st + 2 < nstage) issue(st + 2);
+#else
+    wait_stage(st + 1 < nstage);                 // stage st+1 (if any) was issued after stage st
+    __syncthreads();
+    if (st + 2 < nstage) issue(st + 2);
+#endif
+    preload(st);
+    if (st > 0 && (SPG == 1 || (st & 1) == 0)) count_group();   // the group that ended with stage st-1
+    compute(st);
+  }
+  count_group();
+  if (PL != 32) {
     // dictionary codes make a sequence differ from itself wherever it holds a singleton value:
     // the diagonal is n_hash matches by definition (src/minHash.cpp:161)
     if (I0 - J0 < K2_TILE && J0 - I0 < K2_TILE) {
@@ -451,6 +479,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
         }
     }
   }
+  K2_STAMP(2);
   auto matches = [&](int r, int c) -> uint32_t {  // reference src/minHash.cpp:168-173
     return (uint32_t)n_hash - ((mis[r][c >> 1] >> ((c & 1) * 16)) & 0xffffu);
   };
@@ -466,14 +495,49 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
       for (int c = tid; c <= n_hash; c += K2_THREADS) ratio[c] = (double)c / (double)n_hash;
     __syncthreads();
   }
+  K2_STAMP(6);
   auto widen = [&](uint32_t c) -> double {
     return use_table ? ratio[c] : (double)c / (double)n_hash;
   };
 
   // lane's rows: 32*g + 2*ty + e  <-> index r = 2*g + e ; cols likewise.
+  // Tiles that lie wholly inside the matrix (all but the last tile row / column) take a straight-line
+  // epilogue: no per-element bounds tests, one table read per element, 16-byte stores at immediate
+  // offsets.  The workgroup shares its SIMDs with two others that are in their plane loops, so every
+  // instruction here costs ~3 issue slots: the general path below ran 10 us per tile, this one ~3.
+  const bool interior = I0 + K2_TILE <= (row_end < n ? row_end : n) && J0 + K2_TILE <= n;
   if (F64) {
     double *out = reinterpret_cast<double *>(out_v);
     const bool vec_ok = ((ld & 1) == 0) && ((Jloc & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (use_table && interior && vec_ok) {
+      const char *tb = reinterpret_cast<const char *>(ratio);
+      double v[8][8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t mm = (uint32_t)n_hash * 0x10001u - mis[r][c];          // two match counts (no borrow: each <= n_hash)
+          v[r][2 * c] = *reinterpret_cast<const double *>(tb + ((mm << 3) & 0x7fff8u));
+          v[r][2 * c + 1] = *reinterpret_cast<const double *>(tb + ((mm >> 13) & 0x7fff8u));
+        }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        double *orow = out + (I0 + 32 * (r >> 1) + 2 * ty + (r & 1) + Iloc) * ld + (Jloc + J0 + 2 * tx);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<double2 *>(orow + 32 * g) = make_double2(v[r][2 * g], v[r][2 * g + 1]);
+      }
+      K2_STAMP(7);
+      if (SYM && tid2.ti != tid2.tj) {  // mirrored store (src/minHash.cpp:176)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          double *orow = out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 2 * ty);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<double2 *>(orow + 32 * g) = make_double2(v[2 * g][c], v[2 * g + 1][c]);
+        }
+      }
+      K2_STAMP(3);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
@@ -491,6 +555,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
         }
       }
     }
+    K2_STAMP(7);
     if (SYM && tid2.ti != tid2.tj) {  // mirrored store (src/minHash.cpp:176)
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -512,6 +577,30 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     }
   } else {
     uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
+    const bool vec_ok = ((ld & 1) == 0) && ((Jloc & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
+    if (interior && vec_ok) {   // two adjacent counts per 4-byte store
+      const uint32_t nn = (uint32_t)n_hash * 0x10001u;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint16_t *orow = out + (I0 + 32 * (r >> 1) + 2 * ty + (r & 1) + Iloc) * ld + (Jloc + J0 + 2 * tx);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - mis[r][g];
+      }
+      if (SYM && tid2.ti != tid2.tj) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          uint16_t *orow = out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 2 * ty);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t lo = mis[2 * g][c >> 1], hi = mis[2 * g + 1][c >> 1];
+            const uint32_t pk = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - pk;
+          }
+        }
+      }
+      K2_STAMP(3);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int64_t gi = I0 + 32 * (r >> 1) + 2 * ty + (r & 1);
@@ -539,6 +628,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
       }
     }
   }
+  K2_STAMP(3);
 }
 
 // Lower triangle <- upper triangle (after a gather of upper-triangular rows).
@@ -570,29 +660,35 @@ __global__ __launch_bounds__(256) void k_widen(const uint16_t *__restrict__ in, 
 
 }  // namespace
 
+#ifdef DA_K2_TIMING
+extern "C" int da_debug_set_k2_timing(unsigned long long *d_buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k2_timing), &d_buf, sizeof(d_buf));
+}
+#endif
+
 int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n, int k,
                               int n_hash, const uint32_t *d_seeds, uint32_t *d_sig,
-                              int64_t ld_sig, uint32_t *d_planes, int64_t ld_planes,
-                              hipStream_t stream) {
+                              int64_t ld_sig, hipStream_t stream) {
   if (n <= 0) return DA_OK;
   if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "more than 2^31-1 sequences");
   const size_t lds = 2 * (size_t)(K1_CHUNK + k) * sizeof(uint32_t);
   if (lds > 64 * 1024) return fail(DA_ERR_UNSUPPORTED, "k = %d is larger than the signature kernel supports (k <= 7168)", k);
   dim3 grid((unsigned)n), block(K1_THREADS);
   if (k == 4)
-    hipLaunchKernelGGL(k_minhash_signatures<true>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig, d_planes, ld_planes);
+    hipLaunchKernelGGL(k_minhash_signatures<true>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig);
   else
-    hipLaunchKernelGGL(k_minhash_signatures<false>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig, d_planes, ld_planes);
+    hipLaunchKernelGGL(k_minhash_signatures<false>, grid, block, lds, stream, d_res, d_off, k, n_hash, d_seeds, d_sig, ld_sig);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
 
-int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, int n_hash,
+int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
                       void *d_out, int64_t ld, hipStream_t stream, int plane_bits, int tile_stride, bool upper_only,
                       int fold_q, int64_t fold_w) {
   if (row_end <= row_begin) return DA_OK;
-  if (plane_bits != 16 && plane_bits != 32) return fail(DA_ERR_BAD_ARG, "plane_bits must be 16 or 32 (got %d)", plane_bits);
+  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 16 && plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 16 or 32 (got %d)", plane_bits);
   const int T = (int)ceil_div(n, K2_TILE);
   const int TR = (int)ceil_div(ceil_div(row_end - row_begin, K2_TILE), tile_stride);
   const int64_t ntiles = count_tiles(TR, T, symmetric);
@@ -605,14 +701,19 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int64_t n, in
   if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
 #define DA_K2(SYM, F64, PL)                                                                              \
-  hipLaunchKernelGGL((k_mh_compare<SYM, F64, PL>), grid, block, 0, stream, d_planes, ld_planes, n, n_hash, \
+  hipLaunchKernelGGL((k_mh_compare<SYM, F64, PL>), grid, block, 0, stream, d_planes, n, n_hash, \
                      row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w, band)
 #define DA_K2_PL(PL)                                                                     \
   do {                                                                                   \
     if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true, PL); else DA_K2(true, false, PL); } \
     else           { if (kind == DA_OUT_F64) DA_K2(false, true, PL); else DA_K2(false, false, PL); } \
   } while (0)
-  if (plane_bits == 16) DA_K2_PL(16); else DA_K2_PL(32);
+  switch (plane_bits) {
+    case 8: DA_K2_PL(8); break;
+    case 12: DA_K2_PL(12); break;
+    case 16: DA_K2_PL(16); break;
+    default: DA_K2_PL(32); break;
+  }
 #undef DA_K2_PL
 #undef DA_K2
   DA_HIP_TRY(hipGetLastError());

@@ -43,22 +43,19 @@ def sig_ld(n_hash):
     return int(_capi.load().da_sig_ld(int(n_hash)))
 
 
-def planes_ld(n_hash):
-    return int(_capi.load().da_planes_ld(int(n_hash)))
+def planes_words(n, n_hash):
+    return int(_capi.load().da_mh_planes_words(int(n), int(n_hash)))
 
 
 class Planes:
-    """Operand of mh_compare: the bit-plane tensor plus the number of planes it holds per group of
-    32 hash functions (16: dictionary codes from da_dev_mh_planes, 32: raw signature bits)."""
+    """Operand of mh_compare: the (opaque, blocked) bit-plane buffer plus the number of planes it holds per
+    group of 32 hash functions (8 / 12 / 16: dictionary codes from da_dev_mh_planes, 32: raw signature bits)."""
 
     def __init__(self, tensor, bits):
         self.tensor, self.bits = tensor, int(bits)
 
     def data_ptr(self):
         return self.tensor.data_ptr()
-
-    def stride(self, d):
-        return self.tensor.stride(d)
 
     @property
     def device(self):
@@ -73,51 +70,44 @@ def planes_workspace_bytes(n, n_hash):
     return int(_capi.load().da_mh_planes_workspace_bytes(int(n), int(n_hash)))
 
 
-def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=True, raw_planes=False, work=None):
+def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=True, raw_planes=False, work=None,
+                       min_plane_bits=0):
     """K1 (+ K1b).  Returns (sig, planes): `sig` is the int32 tensor (n, sig_ld(n_hash)) holding the uint32
     signatures in columns [0, n_hash); `planes` is the Planes operand of mh_compare (None if want_planes is
-    False): the signatures' dictionary codes, bit-transposed, 16 planes per 32 hash functions
-    (da_dev_mh_planes; synchronises the stream once), or with raw_planes=True the 32 raw bit planes K1 writes
-    itself.  `planes` / `work` may be preallocated: (n, planes_ld(n_hash)) int32 and
-    planes_workspace_bytes(n, n_hash) uint8."""
+    False), see mh_planes.  raw_planes=True is min_plane_bits=32."""
     lib = _capi.load()
     if not torch.is_tensor(seeds):
         seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32).copy()).to(ds.residues.device)
     _require_cuda(ds.residues, "residues")
     ld = sig_ld(n_hash) if n_hash > 0 else 32
-    dev = ds.residues.device
     if out is None:
-        out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=dev)
-    if isinstance(planes, Planes):
-        planes = planes.tensor
-    if planes is None and want_planes:
-        planes = torch.empty((max(ds.n, 1), 2 * ld), dtype=torch.int32, device=dev)
-    inline = planes is not None and raw_planes
+        out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
     _capi.check(lib.da_dev_minhash_signatures(ds.residues.data_ptr(), ds.offsets.data_ptr(), ds.n, ds.total,
                                               ds.max_len, int(k), int(n_hash), seeds.data_ptr(), out.data_ptr(),
-                                              out.stride(0), planes.data_ptr() if inline else None,
-                                              planes.stride(0) if inline else 0, _stream()))
-    if planes is None:
+                                              out.stride(0), _stream()))
+    if not want_planes and planes is None:
         return out, None
-    if inline:
-        return out, Planes(planes, 32)
-    return out, mh_planes(out, ds.n, n_hash, planes, work)
+    return out, mh_planes(out, ds.n, n_hash, planes, work, 32 if raw_planes else min_plane_bits)
 
 
-def mh_planes(sig, n, n_hash, planes=None, work=None):
-    """K1b.  Signature tensor -> Planes operand (dictionary codes, 16 planes per group, when n <= 131068;
-    raw 32 planes otherwise).  Synchronises the current stream once on the 16-plane route."""
+def mh_planes(sig, n, n_hash, planes=None, work=None, min_plane_bits=0):
+    """K1b.  Signature tensor -> Planes operand: the signatures' exact dictionary codes, bit-transposed, with
+    8 / 12 / 16 planes per 32 hash functions (as few as the data needs, at least min_plane_bits) when
+    n <= 131068; raw 32 planes otherwise or with min_plane_bits=32.  Synchronises the current stream once on
+    the dictionary route.  `planes` / `work` may be preallocated: planes_words(n, n_hash) int32 and
+    planes_workspace_bytes(n, n_hash) uint8."""
     lib = _capi.load()
     _require_cuda(sig, "signatures")
     if isinstance(planes, Planes):
         planes = planes.tensor
     if planes is None:
-        planes = torch.empty((max(n, 1), planes_ld(n_hash)), dtype=torch.int32, device=sig.device)
+        planes = torch.empty(max(planes_words(n, n_hash), 4), dtype=torch.int32, device=sig.device)
     if work is None:
         work = torch.empty(planes_workspace_bytes(n, n_hash), dtype=torch.uint8, device=sig.device)
     bits = ctypes.c_int(0)
-    _capi.check(lib.da_dev_mh_planes(sig.data_ptr(), sig.stride(0), n, int(n_hash), work.data_ptr(), work.numel(),
-                                     planes.data_ptr(), planes.stride(0), ctypes.byref(bits), _stream()))
+    _capi.check(lib.da_dev_mh_planes(sig.data_ptr(), sig.stride(0), n, int(n_hash), int(min_plane_bits),
+                                     work.data_ptr(), work.numel(), planes.data_ptr(), planes.numel(),
+                                     ctypes.byref(bits), _stream()))
     return Planes(planes, bits.value)
 
 
@@ -137,7 +127,7 @@ def mh_compare(planes, n, n_hash, row_begin=0, row_end=None, symmetric=None, kin
     if symmetric is None:
         symmetric = (row_begin == 0 and row_end == n)
     out = _alloc_out(row_end - row_begin, n, kind, planes.device, out)
-    _capi.check(lib.da_dev_mh_compare(planes.data_ptr(), planes.stride(0), planes.bits, n, int(n_hash), row_begin,
+    _capi.check(lib.da_dev_mh_compare(planes.data_ptr(), planes.bits, n, int(n_hash), row_begin,
                                       row_end, 1 if symmetric else 0, kind, out.data_ptr(), out.stride(0), _stream()))
     return out
 

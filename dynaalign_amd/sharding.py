@@ -114,7 +114,7 @@ def finalize_shards(plan, gathered, is_nw, n_hash, out):
 
 def mh_local_block(plan, work, planes, n_hash):
     assert plan.tile == MH_TILE
-    _capi.check(_capi.load().da_dev_mh_compare_shard(planes.data_ptr(), planes.stride(0), planes.bits, plan.n, int(n_hash),
+    _capi.check(_capi.load().da_dev_mh_compare_shard(planes.data_ptr(), planes.bits, plan.n, int(n_hash),
                                                      plan.rank, plan.world, work.local.data_ptr(),
                                                      work.local.stride(0), _stream()))
     return work.local

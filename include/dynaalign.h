@@ -120,44 +120,40 @@ int da_nw_pairs(const uint8_t *residues, const int64_t *offsets, int64_t n,
 
 /* ---- device-pointer entry points (bench / multi-GPU sharding) ------------ */
 
-/* Leading dimension (in uint32 elements) the library uses for signature and
- * bit-plane matrices: n_hash rounded up to a multiple of 32. */
+/* Leading dimension (in uint32 elements) the library uses for signature
+ * matrices: n_hash rounded up to a multiple of 32. */
 int64_t da_sig_ld(int n_hash);
-/* Leading dimension of the bit-plane matrix: 2 * da_sig_ld(n_hash) (two copies per row). */
-int64_t da_planes_ld(int n_hash);
 
 /* K1: signature build.
- *   d_sig    : n rows of ld_sig (>= n_hash) uint32 -- the signatures themselves
- *              (src/minHash.cpp:140-157); columns [n_hash, ld_sig) not written.
- *   d_planes : optional (NULL to skip) n rows of ld_planes uint32, ld_planes a
- *              multiple of 64 and >= da_planes_ld(n_hash): the same signatures
- *              bit-transposed in groups of 32 hash functions (word 32g+p = bit p
- *              of sig[32g .. 32g+31]; hash functions >= n_hash read as 0),
- *              followed at word ld_planes/2 by a second copy with every pair of
- *              planes swapped (word (32g+p)^1).  Operand of the compare kernel. */
+ *   d_sig : n rows of ld_sig (>= n_hash) uint32 -- the signatures themselves
+ *           (src/minHash.cpp:140-157); columns [n_hash, ld_sig) not written. */
 int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n,
                               int64_t total_residues, int64_t max_len,
                               int k, int n_hash, const uint32_t *d_seeds,
-                              uint32_t *d_sig, int64_t ld_sig,
-                              uint32_t *d_planes, int64_t ld_planes, void *stream);
+                              uint32_t *d_sig, int64_t ld_sig, void *stream);
 
 /* K1b: signatures -> operand of the compare kernel.  The compare only asks "equal or not" per
  * hash function (src/minHash.cpp:168-173), so each column of d_sig is re-coded exactly: values
- * occurring >= 2 times get dense 16-bit ids, values occurring once get codes that never match
- * (0xFFFE row side / 0xFFFF column side).  That needs 16 instead of 32 bit planes per group of
- * 32 hash functions and halves the compare's work; it is exact for every input with
- * n <= 131068 (at most n/2 repeated values per column).  Larger n -- or the never-observed
- * overflow of the dictionary's LDS table -- produce the raw 32-plane layout instead.
- *   d_planes      : n rows of ld_planes (>= da_planes_ld(n_hash), multiple of 64) uint32.
- *                   16-plane layout: word 16g+p = bit p of the codes of hash functions
- *                   32g..32g+31; column copy (planes pair-swapped) at word ld_planes/2.
+ * occurring >= 2 times get dense ids, values occurring once get codes that never match (one code
+ * on the row side, another on the column side; the compare kernel forces the diagonal).  The
+ * codes are then bit-transposed per group of 32 hash functions with as many bit planes as the
+ * largest column dictionary needs -- 8, 12 or 16 instead of the 32 of the raw values -- and the
+ * bit-sliced compare does that fraction of the work.  Exact for every input with n <= 131068
+ * (at most n/2 repeated values per column fit 16 bits); larger n -- or the never-observed
+ * overflow of the dictionary's LDS table -- produce the raw 32-plane operand instead.
+ *   min_plane_bits: 0 = as few planes as the data needs; 12 / 16 = at least that many code
+ *                   planes; 32 = raw signature bits (no dictionary).
+ *   d_planes      : 16-byte aligned buffer of planes_words >= da_mh_planes_words(n, n_hash)
+ *                   uint32; opaque (blocked in the order the compare kernel stages it).
  *   d_work        : da_mh_planes_workspace_bytes(n, n_hash) bytes of scratch, 256-byte aligned
- *   plane_bits_out: 16 or 32 -- pass it to da_dev_mh_compare[_shard].
- * Synchronises `stream` once (reads the dictionary's status word) when it takes the 16-bit route.
- * The environment variable DYNAALIGN_PLANE_BITS=32 forces the raw layout (debugging aid). */
+ *   plane_bits_out: 8, 12, 16 or 32 -- pass it to da_dev_mh_compare[_shard].
+ * Synchronises `stream` once (reads the dictionary's status words) on the dictionary route.
+ * The environment variable DYNAALIGN_PLANE_BITS (12, 16, 32) raises min_plane_bits (debugging aid;
+ * it also reaches the host-pointer entry points). */
+int64_t da_mh_planes_words(int64_t n, int n_hash);
 size_t da_mh_planes_workspace_bytes(int64_t n, int n_hash);
-int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash,
-                     void *d_work, size_t work_bytes, uint32_t *d_planes, int64_t ld_planes,
+int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, int min_plane_bits,
+                     void *d_work, size_t work_bytes, uint32_t *d_planes, int64_t planes_words,
                      int *plane_bits_out, void *stream);
 
 /* K2: all-pairs signature compare (bit-sliced: OR over planes of a XOR b, then
@@ -169,9 +165,8 @@ int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_has
  *                    (direct + mirrored), like src/minHash.cpp:175-176.
  *   symmetric == 0 : every (i,j) of the row block is compared (row-sharding).
  * kind selects double or uint16 counts.  Diagonal = 1.0 / n_hash.
- * d_planes: 16-byte aligned bit-plane matrix from da_dev_mh_planes (plane_bits as it reported) or
- * from da_dev_minhash_signatures (plane_bits = 32). */
-int da_dev_mh_compare(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash,
+ * d_planes, plane_bits: from da_dev_mh_planes for the same n and n_hash. */
+int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, int symmetric,
                       int kind, void *d_out, int64_t ld, void *stream);
 
@@ -205,7 +200,7 @@ int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64
  * single-process); the math per pair is unchanged. */
 int64_t da_shard_rows(int64_t n, int world, int is_nw);
 int64_t da_shard_ld(int64_t n, int world, int is_nw);
-int da_dev_mh_compare_shard(const uint32_t *d_planes, int64_t ld_planes, int plane_bits, int64_t n, int n_hash,
+int da_dev_mh_compare_shard(const uint32_t *d_planes, int plane_bits, int64_t n, int n_hash,
                             int rank, int world, uint16_t *d_local, int64_t ld, void *stream);
 int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len,
                     int matrix_id, int gap_open, int gap_ext, int rank, int world,

@@ -29,26 +29,39 @@ def _counts(sig_h):
     return np.stack([(row[None, :] == sig_h).sum(1) for row in sig_h]).astype(np.uint16)
 
 
-def _planes_both(da, res, off, k, n_hash, seed=12345):
+def _bits_needed(sig_h):
+    """planes the library should pick: ids for the values seen >= 2 times in a column, plus 2 singleton codes"""
+    most = 0
+    for h in range(sig_h.shape[1]):
+        _, c = np.unique(sig_h[:, h], return_counts=True)
+        most = max(most, int((c >= 2).sum()))
+    return 8 if most + 2 <= 256 else 12 if most + 2 <= 4096 else 16
+
+
+def _planes_both(da, res, off, k, n_hash, seed=12345, min_bits=0):
     from dynaalign_amd import device
     seeds = da.hash_family_seeds(seed, n_hash)
     ds = device.DeviceSequences(res, off)
-    sig, p16 = device.minhash_signatures(ds, k, n_hash, seeds)
+    sig, pc = device.minhash_signatures(ds, k, n_hash, seeds, min_plane_bits=min_bits)
     _, p32 = device.minhash_signatures(ds, k, n_hash, seeds, raw_planes=True)
-    assert p16.bits == 16 and p32.bits == 32
-    return ds.n, sig[:, :n_hash].cpu().numpy().view(np.uint32), p16, p32
+    assert pc.bits in (8, 12, 16) and pc.bits >= min_bits and p32.bits == 32
+    return ds.n, sig[:, :n_hash].cpu().numpy().view(np.uint32), pc, p32
 
 
 @pytest.mark.parametrize("gen,n", [("uniform_peptides", 1), ("uniform_peptides", 2), ("uniform_peptides", 63),
                                    ("uniform_peptides", 64), ("uniform_peptides", 65), ("uniform_peptides", 1000),
                                    ("h3n2_like", 129), ("h3n2_like", 1500), ("uniform_peptides", 9000)])
 @pytest.mark.parametrize("n_hash", [500, 31, 64])
-def test_codes_give_the_counts_of_the_raw_signatures(da, gen, n, n_hash):
+@pytest.mark.parametrize("min_bits", [0, 12, 16])
+def test_codes_give_the_counts_of_the_raw_signatures(da, gen, n, n_hash, min_bits):
+    """8 / 12 / 16 code planes (whatever the data needs, or forced up) == 32 raw planes == numpy"""
     from dynaalign_amd import device, synth, _capi
     if n >= 9000 and n_hash != 500:
         pytest.skip("one large case is enough")
     res, off = getattr(synth, gen)(n, 20)
-    n, sig_h, p16, p32 = _planes_both(da, res, off, 4, n_hash)
+    n, sig_h, p16, p32 = _planes_both(da, res, off, 4, n_hash, min_bits=min_bits)
+    if min_bits == 0:
+        assert p16.bits == _bits_needed(sig_h)
     c16 = device.mh_compare(p16, n, n_hash, kind=_capi.DA_OUT_COMPACT).cpu().numpy().view(np.uint16)
     c32 = device.mh_compare(p32, n, n_hash, kind=_capi.DA_OUT_COMPACT).cpu().numpy().view(np.uint16)
     assert np.array_equal(c16, c32)
@@ -85,6 +98,7 @@ def test_row_blocks_keep_the_diagonal(da, row_begin, row_end):
     from dynaalign_amd import device, synth, _capi
     res, off = synth.uniform_peptides(700, 20)
     n, sig_h, p16, p32 = _planes_both(da, res, off, 4, 100)
+    assert p16.bits == _bits_needed(sig_h)
     want = _counts(sig_h)[row_begin:row_end]
     for p in (p16, p32):
         got = device.mh_compare(p, n, 100, row_begin, row_end, False, _capi.DA_OUT_COMPACT)
