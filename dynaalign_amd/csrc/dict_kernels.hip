@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_sig_transpose(const uint32_t *__restric
 constexpr int DK_THREADS = 1024;
 constexpr int DK_SLOTS = 16384;        // LDS table slots per key partition (power of two)
 constexpr int DK_PART_KEYS = 8192;     // partitions are sized for <= 50 % load even if every key is distinct
-constexpr int DK_UNROLL = 8;           // independent loads in flight per thread
+constexpr int DK_MAX_PARTS = 16;       // partitions: n <= DA_DICT_MAX_N = 131068 -> ceil(n / 8192) <= 16
 
 // a bijection of uint32 (murmur3's finaliser): partition and slot are taken from the mixed key,
 // so the skew of min-hash VALUES (they crowd near 0) does not reach the table
@@ -61,53 +61,80 @@ static_assert(DK_SLOTS == (1 << 14), "dk_slot assumes 2^14 slots");
 
 // status[0]: 0 ok, 1 a partition overflowed its table, 2 more than 65534 repeated values
 // status[1]: the largest number of repeated values (= ids handed out) in any column
+//
+// One workgroup per hash function (column of sigT).
+//   1. the column's mixed keys are counting-sorted by partition into the scratch arrays
+//      (sz = mixed key, si = sequence index; order inside a partition is arbitrary);
+//   2. per partition: LDS hash table -- first arrival claims a slot, later arrivals of the same
+//      key flag it; flagged slots are numbered (base + scan); every key is looked up again and
+//      its code written to idsT[si].
+// Each key is read four times in all, whatever the number of partitions.
 __global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__restrict__ sigT, int64_t ldT, int64_t n,
-                                                           int R, uint16_t *__restrict__ idsT, int64_t ld_ids,
+                                                           int R, uint32_t *__restrict__ szT, uint32_t *__restrict__ siT,
+                                                           uint16_t *__restrict__ idsT, int64_t ld_ids,
                                                            int *__restrict__ status) {
+  constexpr int NW = DK_THREADS / 64;
   __shared__ uint32_t keys[DK_SLOTS];
   __shared__ uint16_t vals[DK_SLOTS];
-  __shared__ uint32_t wsum[DK_THREADS / 64];
+  __shared__ uint32_t wsum[NW];
+  __shared__ uint32_t cnt[NW][DK_MAX_PARTS];      // keys of partition p seen by wave w, then its write cursor
+  __shared__ uint32_t pbase[DK_MAX_PARTS + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t *col = sigT + (int64_t)blockIdx.x * ldT;
+  uint32_t *sz = szT + (int64_t)blockIdx.x * ldT;
+  uint32_t *si = siT + (int64_t)blockIdx.x * ldT;
   uint16_t *ids = idsT + (int64_t)blockIdx.x * ld_ids;
-  uint32_t base = 0;       // dense ids handed out so far (uniform over the workgroup)
-  bool overflow = false;
 
+  // ---- 1. counting sort by partition (per-wave counters keep the LDS atomics apart)
+  for (int t = tid; t < NW * DK_MAX_PARTS; t += DK_THREADS) (&cnt[0][0])[t] = 0;
+  __syncthreads();
+  for (int64_t i = tid; i < n; i += DK_THREADS) atomicAdd(&cnt[wave][dk_part(dk_mix(col[i]), R)], 1u);
+  __syncthreads();
+  if (tid < R) {                     // cnt[w][p] -> first slot of wave w inside partition p (relative)
+    uint32_t run = 0;
+    for (int w = 0; w < NW; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
+    pbase[tid + 1] = run;            // size of partition tid for now
+  }
+  __syncthreads();
+  if (tid == 0) {
+    pbase[0] = 0;
+    for (int p = 0; p < R; ++p) pbase[p + 1] += pbase[p];
+  }
+  __syncthreads();
+  for (int64_t i = tid; i < n; i += DK_THREADS) {
+    const uint32_t z = dk_mix(col[i]);
+    const int p = dk_part(z, R);
+    const uint32_t pos = pbase[p] + atomicAdd(&cnt[wave][p], 1u);
+    sz[pos] = z;
+    si[pos] = (uint32_t)i;
+  }
+  __syncthreads();                   // the workgroup's own global writes are visible to it from here on
+
+  // ---- 2. one LDS table per partition
+  uint32_t base = 0;                 // dense ids handed out so far (uniform over the workgroup)
+  bool overflow = false;
   for (int r = 0; r < R; ++r) {
+    const uint32_t lo = pbase[r], hi = pbase[r + 1];
     // a mixed key that can never be inserted in this pass marks an empty slot: the smallest z
     // of partition (r+1) % R  (R >= 2)
     const uint32_t q = (uint32_t)((r + 1) % R);
     const uint32_t EMPTY = (uint32_t)((((uint64_t)q << 32) + (uint32_t)R - 1) / (uint32_t)R);
     for (int s = tid; s < DK_SLOTS; s += DK_THREADS) { keys[s] = EMPTY; vals[s] = 0; }
     __syncthreads();
-
-    // ---- insert: first arrival claims a slot, every later arrival of the same key flags it
-    for (int64_t i0 = 0; i0 < n; i0 += (int64_t)DK_THREADS * DK_UNROLL) {
-      uint32_t z[DK_UNROLL];
-      bool act[DK_UNROLL];
-#pragma unroll
-      for (int u = 0; u < DK_UNROLL; ++u) {
-        const int64_t i = i0 + (int64_t)u * DK_THREADS + tid;
-        act[u] = i < n;
-        z[u] = dk_mix(act[u] ? col[i] : 0u);
-        act[u] = act[u] && dk_part(z[u], R) == r;
-      }
-#pragma unroll
-      for (int u = 0; u < DK_UNROLL; ++u) {
-        if (!act[u]) continue;
-        uint32_t s = dk_slot(z[u]);
-        for (int probes = 0;; ++probes) {
-          const uint32_t old = atomicCAS(&keys[s], EMPTY, z[u]);
-          if (old == EMPTY) break;
-          if (old == z[u]) { vals[s] = 1; break; }
-          s = (s + 1) & (DK_SLOTS - 1);
-          if (probes >= DK_SLOTS) { overflow = true; break; }
-        }
+    for (uint32_t j = lo + tid; j < hi; j += DK_THREADS) {
+      const uint32_t z = sz[j];
+      uint32_t s = dk_slot(z);
+      for (int probes = 0;; ++probes) {
+        const uint32_t old = atomicCAS(&keys[s], EMPTY, z);
+        if (old == EMPTY) break;
+        if (old == z) { vals[s] = 1; break; }
+        s = (s + 1) & (DK_SLOTS - 1);
+        if (probes >= DK_SLOTS) { overflow = true; break; }
       }
     }
     __syncthreads();
 
-    // ---- number the repeated keys of this partition: base + exclusive scan over the slots
+    // number the repeated keys of this partition: base + exclusive scan over the slots
     uint32_t mine = 0;
     for (int s = tid; s < DK_SLOTS; s += DK_THREADS) mine += vals[s];
     uint32_t incl = mine;
@@ -118,7 +145,7 @@ __global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__res
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t before = 0, total = 0;
-    for (int w = 0; w < DK_THREADS / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const uint32_t v = wsum[w];
       if (w < wave) before += v;
       total += v;
@@ -131,30 +158,18 @@ __global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__res
     base += total;
     __syncthreads();
 
-    // ---- look every key of the partition up again and emit its code
-    for (int64_t i0 = 0; i0 < n; i0 += (int64_t)DK_THREADS * DK_UNROLL) {
-      uint32_t z[DK_UNROLL];
-      bool act[DK_UNROLL];
-#pragma unroll
-      for (int u = 0; u < DK_UNROLL; ++u) {
-        const int64_t i = i0 + (int64_t)u * DK_THREADS + tid;
-        act[u] = i < n;
-        z[u] = dk_mix(act[u] ? col[i] : 0u);
-        act[u] = act[u] && dk_part(z[u], R) == r;
+    // look every key of the partition up again and emit its code
+    for (uint32_t j = lo + tid; j < hi; j += DK_THREADS) {
+      const uint32_t z = sz[j];
+      uint32_t s = dk_slot(z);
+      uint16_t id = 0xFFFFu;
+      for (int probes = 0; probes <= DK_SLOTS; ++probes) {
+        const uint32_t cur = keys[s];
+        if (cur == z) { id = vals[s]; break; }
+        if (cur == EMPTY) break;                       // only after an overflow
+        s = (s + 1) & (DK_SLOTS - 1);
       }
-#pragma unroll
-      for (int u = 0; u < DK_UNROLL; ++u) {
-        if (!act[u]) continue;
-        uint32_t s = dk_slot(z[u]);
-        uint16_t id = 0xFFFFu;
-        for (int probes = 0; probes <= DK_SLOTS; ++probes) {
-          const uint32_t cur = keys[s];
-          if (cur == z[u]) { id = vals[s]; break; }
-          if (cur == EMPTY) break;                       // only after an overflow
-          s = (s + 1) & (DK_SLOTS - 1);
-        }
-        ids[i0 + (int64_t)u * DK_THREADS + tid] = id;
-      }
+      ids[si[j]] = id;
     }
     __syncthreads();
   }
@@ -246,10 +261,23 @@ __global__ __launch_bounds__(256) void k_sig_to_planes(const uint32_t *__restric
 
 static int64_t dict_ldT(int64_t n) { return ceil_div(n, 64) * 64; }
 
+// carve-up of the workspace: all [n_hash][ldT]
+struct DictWork { uint32_t *sigT, *sz, *si; uint16_t *idsT; int *status; };
+static DictWork dict_work(void *d_work, int64_t n, int n_hash) {
+  const size_t m = (size_t)n_hash * (size_t)dict_ldT(n);
+  DictWork w;
+  w.sigT = static_cast<uint32_t *>(d_work);
+  w.sz = w.sigT + m;
+  w.si = w.sz + m;
+  w.idsT = reinterpret_cast<uint16_t *>(w.si + m);
+  w.status = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(w.idsT + m) + 63) & ~(uintptr_t)63);
+  return w;
+}
+
 size_t mh_planes_workspace_bytes(int64_t n, int n_hash) {
   if (n <= 0 || n_hash <= 0 || n > DA_DICT_MAX_N) return 256;
   const size_t ldT = (size_t)dict_ldT(n);
-  return (size_t)n_hash * ldT * 4 + (size_t)n_hash * ldT * 2 + 256;
+  return (size_t)n_hash * ldT * (4 + 4 + 4 + 2) + 256;   // sigT, sorted keys, their indices, codes, status
 }
 
 // Step 1 (transpose + dictionary): leaves the codes and two status words in the workspace.
@@ -258,17 +286,18 @@ size_t mh_planes_workspace_bytes(int64_t n, int n_hash) {
 int launch_mh_dictionary(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, void *d_work,
                          int **d_status_out, hipStream_t stream) {
   const int64_t ldT = dict_ldT(n);
-  uint32_t *sigT = static_cast<uint32_t *>(d_work);
-  uint16_t *idsT = reinterpret_cast<uint16_t *>(sigT + (size_t)n_hash * ldT);
-  int *status = reinterpret_cast<int *>(reinterpret_cast<char *>(d_work) + (size_t)n_hash * ldT * 6);
-  status = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(status) + 63) & ~(uintptr_t)63);
+  const DictWork w = dict_work(d_work, n, n_hash);
+  uint32_t *sigT = w.sigT;
+  uint16_t *idsT = w.idsT;
+  int *status = w.status;
   *d_status_out = status;
   DA_HIP_TRY(hipMemsetAsync(status, 0, 2 * sizeof(int), stream));
   hipLaunchKernelGGL(k_sig_transpose, dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_hash, 64)), dim3(256), 0,
                      stream, d_sig, ld_sig, n, n_hash, sigT, ldT);
   int R = (int)ceil_div(n, DK_PART_KEYS);
   if (R < 2) R = 2;
-  hipLaunchKernelGGL(k_dictionary, dim3((unsigned)n_hash), dim3(DK_THREADS), 0, stream, sigT, ldT, n, R, idsT, ldT, status);
+  hipLaunchKernelGGL(k_dictionary, dim3((unsigned)n_hash), dim3(DK_THREADS), 0, stream, sigT, ldT, n, R, w.sz, w.si, idsT, ldT,
+                     status);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
@@ -284,7 +313,7 @@ int mh_plane_bits_for(int max_ids) {
 int launch_ids_to_planes(const void *d_work, int64_t n, int n_hash, int plane_bits, uint32_t *d_planes,
                          hipStream_t stream) {
   const int64_t ldT = dict_ldT(n);
-  const uint16_t *idsT = reinterpret_cast<const uint16_t *>(static_cast<const uint32_t *>(d_work) + (size_t)n_hash * ldT);
+  const uint16_t *idsT = dict_work(const_cast<void *>(d_work), n, n_hash).idsT;
   hipLaunchKernelGGL(k_ids_to_planes, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, stream, idsT, ldT, n, n_hash,
                      plane_bits, d_planes);
   DA_HIP_TRY(hipGetLastError());
