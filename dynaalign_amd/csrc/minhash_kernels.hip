@@ -157,6 +157,13 @@ __device__ __forceinline__ uint32_t or_xor(uint32_t d, uint32_t a, uint32_t b) {
   return __builtin_amdgcn_bitop3_b32(d, a, b, 0xF6);
 }
 
+// 16-byte streaming store: the result matrix is written once and never read back by the kernel
+typedef double da_double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store2(double *p, double a, double b) {
+  da_double2_t v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<da_double2_t *>(p));
+}
+
 struct TileId { int ti, tj; bool valid; };
 
 // Enumeration of pair-space tiles.  Tile rows are grouped into bands of
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
       for (int r = 0; r < 8; ++r) {
         double *orow = out + (I0 + 32 * (r >> 1) + 2 * ty + (r & 1) + Iloc) * ld + (Jloc + J0 + 2 * tx);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<double2 *>(orow + 32 * g) = make_double2(v[r][2 * g], v[r][2 * g + 1]);
+        for (int g = 0; g < 4; ++g) nt_store2(orow + 32 * g, v[r][2 * g], v[r][2 * g + 1]);
       }
       K2_STAMP(7);
       if (SYM && tid2.ti != tid2.tj) {  // mirrored store (src/minHash.cpp:176)
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
         for (int c = 0; c < 8; ++c) {
           double *orow = out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 2 * ty);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) *reinterpret_cast<double2 *>(orow + 32 * g) = make_double2(v[2 * g][c], v[2 * g + 1][c]);
+          for (int g = 0; g < 4; ++g) nt_store2(orow + 32 * g, v[2 * g][c], v[2 * g + 1][c]);
         }
       }
       K2_STAMP(3);
@@ -721,48 +728,78 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
 }
 
 // Gathered shards -> final matrix.  G holds, for every rank p, its folded local block
-// (ShardGeom); out[i][j] = widen(G[entry of (min(i,j), max(i,j))]).  (64- and 128-wide tiles with
-// 16-byte stores and an LDS ratio table were tried and were 10-15 % slower than this simple form.)
+// (ShardGeom); out[i][j] = widen(G[entry of (min(i,j), max(i,j))]).  One workgroup per 64 x 64
+// tile on or above the diagonal, enumerated like the compare kernel's tiles (bands of 8 tile rows,
+// column-major inside a band, one id range per XCD): the mirrored 512-byte pieces of 8 consecutive
+// workgroups are 4 KiB of one output row and the direct pieces of a band's next column follow on
+// (row-major tile order: 23.5 ms, this order: 21 ms at N = 100k; a 128 x 128 variant with the
+// compare kernel's 16-byte store pattern and 140 VGPRs ran 30 ms -- too few waves to hide the
+// read -> LDS -> store chain).  64 divides the shard tile (128 / 64), so which rank's block and
+// which folded row a tile reads from is workgroup-uniform integer arithmetic.  MH widens through
+// an LDS table built with the reference's divide.
+template <bool IS_NW>
 __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__restrict__ G, int64_t ld_g, ShardGeom geom,
-                                                          int is_nw, int n_hash, double *__restrict__ out, int64_t ld) {
-  __shared__ uint16_t t[32][33];
-  const int64_t n = geom.n;
-  const int64_t bi = blockIdx.y, bj = blockIdx.x;
-  if (bj < bi) return;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+                                                          int n_hash, double *__restrict__ out, int64_t ld, int TB,
+                                                          int64_t ntiles, int64_t per_xcd) {
+  constexpr int FT = 64, TABLE = 2048;
+  __shared__ uint16_t t[FT][FT + 2];
+  __shared__ double ratio[IS_NW ? 1 : TABLE];
+  const int n = (int)geom.n;
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= ntiles) return;
+  const TileId tt = decode_tile(L, TB, TB, true);
+  if (!tt.valid) return;
+  const int i0 = tt.ti * FT, j0 = tt.tj * FT;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const bool use_table = !IS_NW && n_hash < TABLE;
+  if (use_table)
+    for (int c = threadIdx.x; c <= n_hash; c += 256) ratio[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
   auto widen = [&](uint32_t v) -> double {
-    if (!is_nw) return (double)v / (double)n_hash;                       // src/minHash.cpp:174
+    if (!IS_NW) return use_table ? ratio[v] : (double)v / (double)n_hash;
     const uint32_t ln = v & 255u;
     if (ln == 0) return __longlong_as_double(0xFFF8000000000000ULL);     // 0/0 as on the reference's host
     return (double)(v >> 8) / (double)ln;                                // src/pairwiseSeqAlign.cpp:311
   };
-  for (int r = ty; r < 32; r += 8) {
-    const int64_t i = bi * 32 + r, j = bj * 32 + tx;
-    if (i < n && j < n && j >= i) {
-      const int64_t tr = i / geom.tile;                                  // global tile row, owner tr % world
-      const int q = (int)(tr / geom.world);
-      const bool front = q <= geom.Q - 1 - q;
-      const int64_t lrow = (int64_t)(front ? q : geom.Q - 1 - q) * geom.tile + (i - tr * geom.tile);
-      const int64_t lcol = front ? j - tr * geom.tile : geom.W - n + j;
-      t[r][tx] = G[((tr % geom.world) * geom.rows + lrow) * ld_g + lcol];
-    }
+  // where rows i0 .. i0+63 live: global tile row tr, owner tr % world, folded local row
+  const int tile = geom.tile;
+  const int tr = i0 / tile;
+  const int q = tr / geom.world, owner = tr - q * geom.world;
+  const bool front = q <= geom.Q - 1 - q;
+  const int64_t lrow0 = (int64_t)owner * geom.rows + (int64_t)(front ? q : geom.Q - 1 - q) * tile + (i0 - tr * tile);
+  const int64_t coff = front ? -(int64_t)tr * tile : geom.W - geom.n;
+  const uint16_t *src = G + lrow0 * ld_g + coff + j0 + tx;
+  const int j = j0 + tx;
+  for (int r = ty; r < FT; r += 4) {
+    const int i = i0 + r;
+    if (i < n && j < n && j >= i) t[r][tx] = src[(int64_t)r * ld_g];
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int64_t i = bi * 32 + r, j = bj * 32 + tx;
-    if (i < n && j < n && j >= i) out[i * ld + j] = widen(t[r][tx]);     // upper part as computed
+  double *o = out + (int64_t)i0 * ld + j;
+  for (int r = ty; r < FT; r += 4) {
+    const int i = i0 + r;
+    if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part as computed
   }
-  for (int r = ty; r < 32; r += 8) {
-    const int64_t j = bj * 32 + r, i = bi * 32 + tx;                     // out[j][i] = upper(i, j)
-    if (i < n && j < n && j > i) out[j * ld + i] = widen(t[tx][r]);
+  const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
+  double *om = out + (int64_t)j0 * ld + im;
+  for (int r = ty; r < FT; r += 4) {
+    const int jm = j0 + r;
+    if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
   }
 }
 
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
                             double *d_out, int64_t ld, hipStream_t stream) {
   if (geom.n <= 0) return DA_OK;
-  const unsigned t = (unsigned)ceil_div(geom.n, 32);
-  hipLaunchKernelGGL(k_finalize_sharded, dim3(t, t), dim3(256), 0, stream, d_g, ld_g, geom, is_nw ? 1 : 0, n_hash, d_out, ld);
+  if (geom.n > 0x7fffffffLL || (geom.tile % 64) != 0) return fail(DA_ERR_UNSUPPORTED, "finalize: unsupported geometry");
+  const int TB = (int)ceil_div(geom.n, 64);
+  const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
+  if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
+  const int64_t per_xcd = ceil_div(tiles, 8);
+  const dim3 grid((unsigned)(per_xcd * 8));
+  if (is_nw)
+    hipLaunchKernelGGL(k_finalize_sharded<true>, grid, dim3(256), 0, stream, d_g, ld_g, geom, n_hash, d_out, ld, TB, tiles, per_xcd);
+  else
+    hipLaunchKernelGGL(k_finalize_sharded<false>, grid, dim3(256), 0, stream, d_g, ld_g, geom, n_hash, d_out, ld, TB, tiles, per_xcd);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
