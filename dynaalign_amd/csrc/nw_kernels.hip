@@ -116,18 +116,26 @@ __device__ __forceinline__ double nw_ratio(uint32_t mt, uint32_t ln) {
 }
 
 // ---- "combined key" cell update (fast path) ---------------------------------
-// A cell's state is ONE int32:  score * 2^15 + priority * 2^13 + payload, payload =
-// matches * 128 + length.  Signed comparison orders by score first, then by priority
-// (diagonal 2 > up 1 > left 0 -- exactly the reference's tie-break, :271-279), and the
-// payload of the winner rides along, so the choose-and-propagate step is one v_max3
-// instead of two half-rate compares and two v_cndmask (gfx950 issues add/sub/and/bitop3
-// at twice the rate of cmp/cndmask/max).  Valid while scores stay within 17 bits: the
-// launcher uses it for 0 <= gapOpen, gapExt and gapOpen + 64*gapExt <= 7000 with the
-// "minus infinity" sentinel at -24000 (any value below every reachable score gives the
-// same decisions as the reference's INT_MIN/2; the int32 kernel covers everything else).
+// A cell's state is ONE int32:  score' * 2^15 + priority * 2^13 + payload, payload =
+// matches * 128 + D, D = number of diagonal moves on the path.  Signed comparison orders by
+// score first, then by priority (diagonal 2 > up 1 > left 0 -- exactly the reference's
+// tie-break, :271-279), and the payload of the winner rides along, so the choose-and-propagate
+// step is one v_max3 instead of two half-rate compares and two v_cndmask (gfx950 issues
+// add/sub/and/bitop3 at twice the rate of cmp/cndmask/max).
+// Scores are kept in a frame that moves with the cell: score'(r,c) = score(r,c) + (r+c)*gapExt.
+// All three candidates of a cell are in the same frame, so every decision is unchanged, but a
+// gap EXTENSION costs nothing any more (Ix' = max(M' + (ge - goe), Ix'): add + max instead of
+// sub + sub + max) and the diagonal's 2*ge goes into the score table.  Likewise the alignment
+// length is not carried: every move adds one column, a diagonal move consumes two indices, so
+// length = r + c - D and only diagonal moves touch the payload (through the table).  10 VALU
+// ops + 1 LDS read per cell (12 + 1 before the moving frame).
+// Valid while scores stay within 17 bits: the launcher uses it for 0 <= gapOpen, gapExt and
+// gapOpen + 64*gapExt <= 7000 with the "minus infinity" sentinel at -24000 (any value below every
+// reachable score gives the same decisions as the reference's INT_MIN/2; the frame moves it by at
+// most 64*gapExt; the int32 kernel covers everything else).
 // Bit budget per length class (the launcher checks the penalty limit):
-//   <= 32 residues: length 7 bits, matches 6 bits -> score 17 bits, sentinel -24000, gapOpen + 64*gapExt <= 7000
-//   <= 64 residues: length 8 bits, matches 7 bits -> score 15 bits, sentinel  -6000, gapOpen + 128*gapExt <= 2500
+//   <= 32 residues: D 7 bits, matches 6 bits -> score 17 bits, sentinel -24000, gapOpen + 64*gapExt <= 7000
+//   <= 64 residues: D 8 bits, matches 7 bits -> score 15 bits, sentinel  -6000, gapOpen + 128*gapExt <= 2500
 template <int NMAX> struct CKBits {
   static constexpr int LB = NMAX <= 32 ? 7 : 8;              // bits of the alignment length
   static constexpr int S = NMAX <= 32 ? 13 : 15;             // payload bits (matches << LB | length)
@@ -138,28 +146,28 @@ template <int NMAX> struct CKBits {
   static constexpr int GAP_LIMIT = NMAX <= 32 ? 7000 : 2500; // gapOpen + 2*NMAX*gapExt must stay below
 };
 
-//   VM[c] : combined M[r-1][c] (priority cleared)         XP[c] : Ix[r-1][c]*2^15 | payload of cell (r-1,c)
+//   VM[c] : combined best'[r-1][c] (priority cleared)     XP[c] : Ix'[r-1][c]*2^15 | priority 1 | payload of cell (r-1,c)
 template <int NMAX, bool FIRST>
 __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMAX], const uint32_t (&boff)[NMAX],
                                           const char *tab_row, int32_t vm_diag0, int32_t vm_left0, int32_t yp_left0,
-                                          int32_t cxa, int32_t cxb, int32_t cya, int32_t cyb, int32_t ixf_first,
-                                          int32_t low_mask, int32_t pri_clear) {
+                                          int32_t kx, int32_t ky, int32_t ixf_first, int32_t pay_mask, int32_t pri_clear) {
   int32_t vmd = vm_diag0, vml = vm_left0, ypl = yp_left0;
 #pragma unroll
   for (int c = 0; c < NMAX; ++c) {
     const int32_t e = *reinterpret_cast<const int32_t *>(tab_row + boff[c]);
-    // up: max(M-goe, Ix-ge), priority 1, payload of the cell above + 1     (reference :255-257, :273-275)
-    const int32_t ixf = FIRST ? ixf_first + c : max(VM[c] - cxa, XP[c] - cxb);
-    // left: max(M-goe, Iy-ge), priority 0, payload of the cell to the left + 1        (:260-262, :276-278)
-    const int32_t iyf = max(vml - cya, ypl - cyb);
-    const int32_t vd = vmd + e;                       // diagonal, priority 2, payload + 1 (+128 on a match)  (:265-271)
+    // up: max(M-goe, Ix-ge), priority 1, payload of the cell above            (reference :255-257, :273-275)
+    const int32_t ixf = FIRST ? ixf_first : max(VM[c] + kx, XP[c]);
+    // left: max(M-goe, Iy-ge), priority 0, payload of the cell to the left             (:260-262, :276-278)
+    const int32_t iyf = max(vml + ky, ypl);
+    const int32_t vd = vmd + e;                       // diagonal, priority 2, D + 1 (+128 on a match)  (:265-271)
     const int32_t w = max(max(vd, ixf), iyf);         // v_max3_i32
     const int32_t vmn = w & pri_clear;
     vmd = VM[c];
     VM[c] = vmn;
-    // (vmn & LOW) | (ixf & ~LOW) as one full-rate v_bitop3 (S0=0xF0,S1=0xCC,S2=0xAA: (S1&S2)|(S0&~S2) = 0xD8)
-    XP[c] = __builtin_amdgcn_bitop3_b32(ixf, vmn, low_mask, 0xD8);
-    ypl = __builtin_amdgcn_bitop3_b32(iyf, vmn, low_mask, 0xD8);
+    // (vmn & PAY) | (ixf & ~PAY) as one full-rate v_bitop3 (S0=0xF0,S1=0xCC,S2=0xAA: (S1&S2)|(S0&~S2) = 0xD8):
+    // the gap state's score (and its own priority bits) with the payload of the cell it leaves
+    XP[c] = __builtin_amdgcn_bitop3_b32(ixf, vmn, pay_mask, 0xD8);
+    ypl = __builtin_amdgcn_bitop3_b32(iyf, vmn, pay_mask, 0xD8);
     vml = vmn;
   }
 }
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   for (int e = threadIdx.x; e < 576; e += K3_THREADS) {
     const int a = e / 24, b = e - a * 24;
     if (CK) {
-      tabk[e] = ((int32_t)table.s[e] << CKBits<NMAX>::S2) + (2 << CKBits<NMAX>::S) + 1 + ((a == b) ? (1 << CKBits<NMAX>::LB) : 0);
+      tabk[e] = (((int32_t)table.s[e] + 2 * ge) << CKBits<NMAX>::S2) + (2 << CKBits<NMAX>::S) + 1 + ((a == b) ? (1 << CKBits<NMAX>::LB) : 0);
     } else {
       tab[e].s_goe = (int32_t)table.s[e] + goe;
       tab[e].inc = 1u + ((a == b) ? 0x10000u : 0u);  // equal index <=> equal residue byte (:291-293)
@@ -283,35 +291,37 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     int32_t sc;
     if constexpr (CK) {
       constexpr int CK_S = CKBits<NMAX>::S, CK_S2 = CKBits<NMAX>::S2, CK_LB = CKBits<NMAX>::LB;
-      constexpr int32_t CK_LOW = CKBits<NMAX>::LOW, CK_PRI = CKBits<NMAX>::PRI, CK_NEG = CKBits<NMAX>::NEG;
-      // row 0 (reference :222-235) in combined form: only its max(M,Ix,Iy) feeds row 1's diagonal
+      constexpr int32_t CK_PRI = CKBits<NMAX>::PRI, CK_NEG = CKBits<NMAX>::NEG;
+      // row 0 (reference :222-235) in combined form: only its max(M,Ix,Iy) feeds row 1's diagonal.
+      // Iy[0][c+1] = -go - c*ge, in the moving frame (+ (c+1)*ge) the constant ge - go; no diagonal moves yet
       int32_t VM[NMAX], XP[NMAX];
 #pragma unroll
       for (int c = 0; c < NMAX; ++c) {
-        VM[c] = ((-go - c * ge) << CK_S2) | (c + 1);   // Iy[0][c+1], payload (0 matches, length c+1)
+        VM[c] = (ge - go) << CK_S2;
         XP[c] = 0;                                      // Ix[0][.] = -inf is handled by FIRST
       }
       // wave-uniform constants are parked in VGPRs: an SGPR source halves v_bitop3's issue rate
       auto in_vgpr = [](int32_t x) { int32_t v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; };
-      const int32_t cxa = in_vgpr((goe << CK_S2) - (1 << CK_S) - 1), cxb = in_vgpr((ge << CK_S2) - (1 << CK_S) - 1);
-      const int32_t cya = in_vgpr((goe << CK_S2) - 1), cyb = in_vgpr((ge << CK_S2) - 1);
-      const int32_t low_mask = in_vgpr(CK_LOW), pri_clear = in_vgpr(~CK_PRI);
-      // Ix[1][c] = max(NEG-goe, NEG-ge), priority 1, payload (0, c+1)+... = length (c+1)+1 added per column
-      const int32_t ixf_first = ((CK_NEG - min(goe, ge)) << CK_S2) + (1 << CK_S) + 2;
+      const int32_t kx = in_vgpr(((ge - goe) << CK_S2) + (1 << CK_S));   // open a gap from M': -goe, +ge of the frame, priority 1
+      const int32_t ky = in_vgpr((ge - goe) << CK_S2);                   // same to the left, priority 0
+      const int32_t pay_mask = in_vgpr((1 << CK_S) - 1), pri_clear = in_vgpr(~CK_PRI);
+      // Ix[1][c] = max(NEG-goe, NEG-ge), priority 1, payload of row 0 (nothing)
+      const int32_t ixf_first = ((CK_NEG - min(goe, ge)) << CK_S2) + (1 << CK_S);
       for (int32_t r = 1; r <= m; ++r) {
         // (making this offset opaque to the compiler turns the per-cell v_mad into a v_add but lets it
         // hoist all 20 lookups: 141 VGPRs / 3 waves per SIMD and 15 % slower -- measured, not kept)
         const uint32_t row_off = (uint32_t)rowcodes[lr][r - 1] * (24u * (uint32_t)sizeof(int32_t));
         const char *tab_row = tab_bytes + row_off;
-        // column 0 of rows r-1 and r (reference :224-229): max(M,Ix,Iy)[r-1][0] and M = Iy = -inf at (r,0)
-        const int32_t vm_diag0 = (r == 1) ? 0 : (((-go - (r - 2) * ge) << CK_S2) | (r - 1));
-        const int32_t left0 = (CK_NEG << CK_S2) | r;
+        // column 0 of rows r-1 and r (reference :224-229): max(M,Ix,Iy)[r-1][0] = Ix = -go - (r-2)*ge (frame:
+        // ge - go) and M = Iy = -inf at (r,0)
+        const int32_t vm_diag0 = (r == 1) ? 0 : ((ge - go) << CK_S2);
+        const int32_t left0 = CK_NEG << CK_S2;
         if (r == 1)
-          nw_row_ck<NMAX, true>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask, pri_clear);
+          nw_row_ck<NMAX, true>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
         else
-          nw_row_ck<NMAX, false>(VM, XP, boff, tab_row, vm_diag0, left0, left0, cxa, cxb, cya, cyb, ixf_first, low_mask, pri_clear);
+          nw_row_ck<NMAX, false>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
       }
-      // ---- cell (m, nj)
+      // ---- cell (m, nj): length = m + nj - D, score = score' - (m + nj)*ge
       mt = 0; ln = (uint32_t)m;                     // nj == 0: column-0 boundary
       sc = (m == 0) ? 0 : NEG;
       if (m == 0) {
@@ -320,7 +330,11 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
       } else {
 #pragma unroll
         for (int c = 0; c < NMAX; ++c)
-          if (nj == c + 1) { mt = ((uint32_t)VM[c] >> CK_LB) & ((1u << (CK_S - CK_LB)) - 1u); ln = (uint32_t)VM[c] & ((1u << CK_LB) - 1u); sc = VM[c] >> CK_S2; }
+          if (nj == c + 1) {
+            mt = ((uint32_t)VM[c] >> CK_LB) & ((1u << (CK_S - CK_LB)) - 1u);
+            ln = (uint32_t)(m + nj) - ((uint32_t)VM[c] & ((1u << CK_LB) - 1u));
+            sc = (VM[c] >> CK_S2) - (m + nj) * ge;
+          }
       }
     } else {
     // row 0 of the DP (reference :222-235)
