@@ -141,7 +141,6 @@ constexpr int K2_TILE = 128;
 constexpr int K2_GROUP = 32;         // hash functions per bit-plane group (= planes per group)
 // planes per LDS stage and 16-byte segments per row per stage depend on the plane count PL of the
 // kernel instance: PL = 32 -> 16 planes (half a group), PL = 16 / 12 / 8 -> the whole group
-constexpr int K2_NSTAGE = 3;         // LDS ring depth
 constexpr int K2_BAND = 8;           // tile rows per L2-resident band
 constexpr int K2_THREADS = 256;
 
@@ -163,6 +162,10 @@ __device__ __forceinline__ void nt_store2(double *p, double a, double b) {
   da_double2_t v = {a, b};
   __builtin_nontemporal_store(v, reinterpret_cast<da_double2_t *>(p));
 }
+
+#ifndef K2_RING_DEPTH
+#define K2_RING_DEPTH(PL) 3
+#endif
 
 struct TileId { int ti, tj; bool valid; };
 
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   constexpr int SEGS = SP / 4;                   // 16-byte segments per row per stage
   constexpr int SPG = PL / SP;                   // stages per group: 2 (PL = 32) or 1
   constexpr int STAGE_UNITS = 2 * K2_TILE * SEGS;
+  constexpr int K2_NSTAGE = K2_RING_DEPTH(PL);   // LDS ring depth
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[K2_NSTAGE * STAGE_UNITS];
 
   // ---- which tile.  Blocks b and b+8 share an XCD (speed only).
@@ -354,12 +358,16 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
                    :: "v"(g), "s"(base + (uint32_t)(q * 64 * sizeof(uint4))) : "memory", "m0");
     }
   };
-  // before the barrier that opens stage s: its SEGS copies must have landed; those of stage s+1 may still fly
-  auto wait_stage = [&](bool younger_in_flight) {
-    if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (SEGS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (SEGS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  // before the barrier that opens stage s: its SEGS copies must have landed; those of the `younger`
+  // stages issued after it may still fly
+  auto wait_stage = [&](int younger) {
+    const int outstanding = younger * SEGS;
+    if (outstanding >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (outstanding == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (outstanding == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (outstanding == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (outstanding == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   uint32_t mis[8][4];  // mismatch counters, two 16-bit counters per register (columns 2j, 2j+1)
@@ -454,19 +462,15 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   // wait_stage: this wave's copies for the stage have landed; the barrier: so have everyone's, and
   // nobody still reads the ring slot the next issue() overwrites (it was consumed two stages ago).
   K2_STAMP(1);
-  issue(0);
-  if (nstage > 1) issue(1);
+  constexpr int AHEAD = K2_NSTAGE - 1;           // stages in flight ahead of the one being computed
+#pragma unroll
+  for (int st = 0; st < AHEAD; ++st)
+    if (st < nstage) issue(st);
   for (int st = 0; st < nstage; ++st) {
-#if defined(DA_K2_EXP_NODMA)      // timing experiments only (wrong results): what do the copies / the barrier cost?
-    if (st < 2) { wait_stage(st + 1 < nstage); __syncthreads(); }
-#elif defined(DA_K2_EXP_NOBARRIER)
-    wait_stage(st + 1 < nstage);
-    if (st + 2 < nstage) issue(st + 2);
-#else
-    wait_stage(st + 1 < nstage);                 // stage st+1 (if any) was issued after stage st
+    const int left = nstage - 1 - st;            // stages after this one
+    wait_stage(left < AHEAD - 1 ? left : AHEAD - 1);
     __syncthreads();
-    if (st + 2 < nstage) issue(st + 2);
-#endif
+    if (st + AHEAD < nstage) issue(st + AHEAD);
     preload(st);
     if (st > 0 && (SPG == 1 || (st & 1) == 0)) count_group();   // the group that ended with stage st-1
     compute(st);
