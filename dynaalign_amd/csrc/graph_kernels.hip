@@ -10,6 +10,8 @@
 // (SURVEY 8(f)-1).  Both kernels stream the compact uint16 count matrix K2 produces (HBM-bound).
 #include "da_common.hpp"
 
+#include <algorithm>
+
 namespace da {
 namespace {
 
@@ -48,40 +50,77 @@ __device__ __forceinline__ bool locate_tile(const Layout &lay, int64_t L, int T,
   return true;
 }
 
+// One 128 x 128 tile per workgroup: thread t reads, in 8 passes, 8 consecutive counts (16 bytes) of row
+// 16*pass + t/16 at columns 8*(t%16) -- a wave-wide load covers 4 rows x 256 B.  Falls back to 2-byte loads
+// when the rows are not 16-byte aligned (odd n / ld) or the tile crosses the matrix edge.
+struct TileRows { uint32_t w[8][4]; };   // [pass][4 dwords = 8 counts]; 0xFFFF marks "not an element"
+
+__device__ __forceinline__ void load_tile(const uint16_t *__restrict__ m, int64_t ld, int64_t n, int64_t I0, int64_t J0,
+                                          int64_t roff, int64_t coff, bool diag_tile, bool keep_diagonal, TileRows &t) {
+  const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 8;
+  const int64_t j0 = J0 + tc;
+  const bool inside = I0 + G_TILE <= n && J0 + G_TILE <= n;
+  const bool aligned = ((ld & 7) == 0) && (((J0 + coff) & 7) == 0) && ((reinterpret_cast<uintptr_t>(m) & 15) == 0);
+  if (inside && aligned && !diag_tile) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(m + (I0 + 16 * p + tr + roff) * ld + j0 + coff);
+      t.w[p][0] = v.x; t.w[p][1] = v.y; t.w[p][2] = v.z; t.w[p][3] = v.w;
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int64_t i = I0 + 16 * p + tr;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t lo = 0xFFFFu, hi = 0xFFFFu;
+      const int64_t j = j0 + e;
+      if (i < n && j < n && (j > i || (keep_diagonal && j == i))) lo = m[(i + roff) * ld + j + coff];
+      if (i < n && j + 1 < n && (j + 1 > i || (keep_diagonal && j + 1 == i))) hi = m[(i + roff) * ld + j + 1 + coff];
+      t.w[p][e >> 1] = lo | (hi << 16);
+    }
+  }
+}
+__device__ __forceinline__ uint32_t tile_elem(const TileRows &t, int p, int e) {
+  return (t.w[p][e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+}
+
 // hist[v] += number of pairs i < j with m[i][j] == v
 __global__ __launch_bounds__(G_THREADS) void k_upper_histogram(const uint16_t *__restrict__ m, int64_t ld, int64_t n,
                                                                int nbins, unsigned long long *__restrict__ hist, int T,
-                                                               Layout lay) {
+                                                               Layout lay, int64_t ntiles) {
   __shared__ unsigned int lh[G_LDS_BINS];
   const bool use_lds = nbins <= G_LDS_BINS;
   if (use_lds)
     for (int b = threadIdx.x; b < nbins; b += G_THREADS) lh[b] = 0;
   __syncthreads();
-  int ti, tj;
-  int64_t roff, coff;
-  const bool live = locate_tile(lay, blockIdx.x, T, ti, tj, roff, coff);   // block-uniform
-  const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
-  const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;  // 128 columns x 2 rows per pass
-  const int64_t j = J0 + cx;
   // The overwhelmingly common value is 0 (unrelated peptides share no k-mer): counted in a register,
   // not with 64 lanes hammering one LDS word (same-address atomics serialise).
-  unsigned zeros = 0;
-  for (int r = ry; live && r < G_TILE; r += 2) {
-    const int64_t i = I0 + r;
-    if (i < n && j < n && j > i) {
-      const unsigned v = m[(i + roff) * ld + j + coff];
-      if (v == 0) ++zeros;
-      else if (v < (unsigned)nbins) {
-        if (use_lds) atomicAdd(&lh[v], 1u);
-        else atomicAdd(&hist[v], 1ull);
+  unsigned long long zeros = 0;
+  // persistent workgroups: the LDS histogram is cleared and flushed once per workgroup, not once per tile
+  for (int64_t L = blockIdx.x; L < ntiles; L += gridDim.x) {
+    int ti, tj;
+    int64_t roff, coff;
+    if (!locate_tile(lay, L, T, ti, tj, roff, coff)) continue;             // block-uniform
+    TileRows t;
+    load_tile(m, ld, n, (int64_t)ti * G_TILE, (int64_t)tj * G_TILE, roff, coff, ti == tj, false, t);
+    unsigned z = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned v = tile_elem(t, p, e);
+        if (v == 0) ++z;
+        else if (v < (unsigned)nbins) {             // 0xFFFF (not an element) never is: nbins <= 65535
+          if (use_lds) atomicAdd(&lh[v], 1u);
+          else atomicAdd(&hist[v], 1ull);
+        }
       }
-    }
+    zeros += z;
   }
   for (int o = 32; o > 0; o >>= 1) zeros += __shfl_down(zeros, o);          // wave sum
-  if ((threadIdx.x & 63) == 0 && zeros) {
-    if (use_lds) atomicAdd(&lh[0], zeros);
-    else atomicAdd(&hist[0], (unsigned long long)zeros);
-  }
+  if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&hist[0], zeros);
   __syncthreads();
   if (use_lds)
     for (int b = threadIdx.x; b < nbins; b += G_THREADS)
@@ -91,7 +130,7 @@ __global__ __launch_bounds__(G_THREADS) void k_upper_histogram(const uint16_t *_
 // append (i, j, v) for every i <= j (diagonal optional) whose value v is flagged in keep[].
 // One global atomic per 128x128 tile (a single counter word saturates near 90 atomics/us, so
 // per-wave reservations -- 78 M of them at N = 100k -- would serialise the whole kernel):
-// every thread scans its column strip, the workgroup scans the per-thread counts in LDS, one
+// every thread flags its 64 elements, the workgroup scans the per-thread counts in LDS, one
 // lane reserves the tile's run of slots, threads then write their own contiguous sub-runs.
 __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__restrict__ m, int64_t ld, int64_t n,
                                                              const uint8_t *__restrict__ keep, int nbins,
@@ -105,16 +144,16 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
   int64_t roff, coff;
   if (!locate_tile(lay, blockIdx.x, T, ti, tj, roff, coff)) return;       // block-uniform
   const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
-  const int cx = threadIdx.x & 127, ry = threadIdx.x >> 7;   // column cx, rows ry, ry+2, ...
-  const int64_t j = J0 + cx;
-  unsigned long long kept = 0;                               // bit q <-> row ry + 2q
-  for (int q = 0; q < G_TILE / 2; ++q) {
-    const int64_t i = I0 + ry + 2 * q;
-    if (i < n && j < n && (j > i || (include_diagonal && j == i))) {
-      const unsigned v = m[(i + roff) * ld + j + coff];
-      if (v < (unsigned)nbins && keep[v] != 0) kept |= 1ull << q;
+  TileRows t;
+  load_tile(m, ld, n, I0, J0, roff, coff, ti == tj, include_diagonal != 0, t);
+  unsigned long long kept = 0;                               // bit 8*pass + e
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned v = tile_elem(t, p, e);
+      if (v < (unsigned)nbins && keep[v] != 0) kept |= 1ull << (8 * p + e);
     }
-  }
   const unsigned mine = (unsigned)__popcll(kept);
   scan[threadIdx.x] = mine;
   __syncthreads();
@@ -129,17 +168,20 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
   if (threadIdx.x == 0) tile_base = atomicAdd(count, (unsigned long long)total);
   __syncthreads();
   unsigned long long slot = tile_base + (scan[threadIdx.x] - mine);
-  for (int q = 0; q < G_TILE / 2; ++q) {
-    if (kept & (1ull << q)) {
-      const int64_t i = I0 + ry + 2 * q;
-      if ((long long)slot < capacity) {
-        ei[slot] = (int32_t)i;
-        ej[slot] = (int32_t)j;
-        ev[slot] = m[(i + roff) * ld + j + coff];
+  const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 8;
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (kept & (1ull << (8 * p + e))) {
+        if ((long long)slot < capacity) {
+          ei[slot] = (int32_t)(I0 + 16 * p + tr);
+          ej[slot] = (int32_t)(J0 + tc + e);
+          ev[slot] = (uint16_t)tile_elem(t, p, e);
+        }
+        ++slot;
       }
-      ++slot;
     }
-  }
 }
 
 }  // namespace
@@ -156,11 +198,13 @@ static Layout make_layout(int64_t n, int rank, int world) {
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
                            hipStream_t stream, int rank, int world) {
   if (n <= 1) return DA_OK;
+  if (nbins > 65535) return fail(DA_ERR_UNSUPPORTED, "histogram of uint16 counts: at most 65535 bins (value 65535 is reserved)");
   const int T = (int)ceil_div(n, G_TILE);
   const Layout lay = make_layout(n, rank, world);
   const int64_t tiles = world > 0 ? (int64_t)lay.g.Q * T : (int64_t)T * (T + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
-  hipLaunchKernelGGL(k_upper_histogram, dim3((unsigned)tiles), dim3(G_THREADS), 0, stream, d_m, ld, n, nbins, d_hist, T, lay);
+  const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * 16);
+  hipLaunchKernelGGL(k_upper_histogram, dim3(grid), dim3(G_THREADS), 0, stream, d_m, ld, n, nbins, d_hist, T, lay, tiles);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
@@ -169,6 +213,7 @@ int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8
                          bool include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
                          unsigned long long *d_count, hipStream_t stream, int rank, int world) {
   if (n <= 0) return DA_OK;
+  if (nbins > 65535) return fail(DA_ERR_UNSUPPORTED, "edge extraction from uint16 counts: at most 65535 bins (value 65535 is reserved)");
   const int T = (int)ceil_div(n, G_TILE);
   const Layout lay = make_layout(n, rank, world);
   const int64_t tiles = world > 0 ? (int64_t)lay.g.Q * T : (int64_t)T * (T + 1) / 2;
