@@ -483,6 +483,119 @@ int da_quantile_type7(const uint64_t *hist, const double *values, int nbins, dou
   return DA_OK;
 }
 
+static int nw_validate(const uint8_t *residues, const int64_t *offsets, int64_t n);
+
+// Shared tail of the *_edges entry points: d_cnt is the dense n x n uint16 code matrix, d_hist the
+// histogram of its strict upper triangle (nbins codes), values[b] the similarity a code stands for.
+//   threshold <- quantile(S[upper.tri(S)], thresh_p)   (R type 7, R/clusterbreak.R:219)
+//   S[S < threshold] <- 0; a zero weight is no edge     (:221; igraph, weighted = TRUE)
+// The diagonal (1.0) always survives.  Edges come back sorted by (i, j).
+static int edges_from_counts(const uint16_t *d_cnt, int64_t n, int nbins, const unsigned long long *d_hist,
+                             const std::vector<double> &values, double thresh_p, double *threshold_out,
+                             int64_t *n_edges_out, int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+  int rc;
+  std::vector<uint64_t> h(nbins);
+  DA_HIP_TRY(hipMemcpy(h.data(), d_hist, (size_t)nbins * 8, hipMemcpyDeviceToHost));
+  // order statistics need the codes in ascending order of their VALUE (MH: already so; NW: ratios)
+  std::vector<int> order(nbins);
+  for (int b = 0; b < nbins; ++b) order[b] = b;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return values[a] < values[b]; });
+  std::vector<uint64_t> hs(nbins);
+  std::vector<double> vs(nbins);
+  for (int b = 0; b < nbins; ++b) { hs[b] = h[order[b]]; vs[b] = values[order[b]]; }
+  double thr;
+  if ((rc = da_quantile_type7(hs.data(), vs.data(), nbins, thresh_p, &thr)) != DA_OK) return rc;
+  *threshold_out = thr;
+  std::vector<uint8_t> kp(nbins);
+  int64_t n_edges = n;                                                       // the diagonal (1.0) always survives
+  for (int b = 0; b < nbins; ++b) {
+    kp[b] = (values[b] != 0.0 && !(values[b] < thr)) ? 1 : 0;
+    if (kp[b]) n_edges += (int64_t)h[b];
+  }
+  *n_edges_out = n_edges;
+  if (!ei && !ej && !ew) return DA_OK;                                       // size query
+  if (!ei || !ej || !ew) return fail(DA_ERR_BAD_ARG, "NULL edge buffer");
+  if (capacity < n_edges) return fail(DA_ERR_BAD_ARG, "edge buffers hold %lld entries, %lld needed", (long long)capacity,
+                                      (long long)n_edges);
+  if (n_edges == 0) return DA_OK;
+  DevBuf keep, cnt_edges, di, dj, dv;
+  if ((rc = keep.alloc((size_t)nbins)) != DA_OK) return rc;
+  if ((rc = cnt_edges.alloc(8)) != DA_OK) return rc;
+  if ((rc = di.alloc((size_t)n_edges * 4)) != DA_OK) return rc;
+  if ((rc = dj.alloc((size_t)n_edges * 4)) != DA_OK) return rc;
+  if ((rc = dv.alloc((size_t)n_edges * 2)) != DA_OK) return rc;
+  DA_HIP_TRY(hipMemcpy(keep.p, kp.data(), (size_t)nbins, hipMemcpyHostToDevice));
+  DA_HIP_TRY(hipMemset(cnt_edges.p, 0, 8));
+  if ((rc = launch_extract_edges(d_cnt, n, n, keep.as<uint8_t>(), nbins, true, di.as<int32_t>(), dj.as<int32_t>(),
+                                 dv.as<uint16_t>(), n_edges, cnt_edges.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
+  uint64_t got = 0;
+  DA_HIP_TRY(hipMemcpy(&got, cnt_edges.p, 8, hipMemcpyDeviceToHost));
+  if ((int64_t)got != n_edges) return fail(DA_ERR_HIP, "edge count mismatch: histogram says %lld, extraction found %llu",
+                                           (long long)n_edges, (unsigned long long)got);
+  std::vector<int32_t> hi_(n_edges), hj_(n_edges);
+  std::vector<uint16_t> hv_(n_edges);
+  DA_HIP_TRY(hipMemcpy(hi_.data(), di.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost));
+  DA_HIP_TRY(hipMemcpy(hj_.data(), dj.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost));
+  DA_HIP_TRY(hipMemcpy(hv_.data(), dv.p, (size_t)n_edges * 2, hipMemcpyDeviceToHost));
+  // the device appends in arrival order; hand the edges back sorted by (i, j)
+  std::vector<int64_t> ord(n_edges);
+  for (int64_t e = 0; e < n_edges; ++e) ord[e] = e;
+  std::sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) {
+    return hi_[a] != hi_[b] ? hi_[a] < hi_[b] : hj_[a] < hj_[b];
+  });
+  for (int64_t e = 0; e < n_edges; ++e) {
+    ei[e] = hi_[ord[e]];
+    ej[e] = hj_[ord[e]];
+    ew[e] = values[hv_[ord[e]]];
+  }
+  return DA_OK;
+}
+
+// similarityNW + clusterbreak's threshold step as an edge list.  The uint16 code (matches << 8 | length)
+// takes few distinct values, so the same histogram / quantile / extraction path as for MinHash applies;
+// value(code) = matches / length with the reference's divide (src/pairwiseSeqAlign.cpp:311).
+int da_similarity_nw_edges(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name,
+                           int gap_open, int gap_ext, double thresh_p, double *threshold_out, int64_t *n_edges_out,
+                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+  const int mid = da_matrix_id(matrix_name);  // reference :338 -> :190-206, before anything else
+  if (mid < 0) return DA_ERR_BAD_MATRIX;
+  if (!residues || !threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (n < 2) return fail(DA_ERR_BAD_ARG, "the threshold is a quantile of the strict upper triangle: need >= 2 sequences");
+  if (!(thresh_p >= 0.0 && thresh_p <= 1.0)) return fail(DA_ERR_BAD_ARG, "thresh_p must be in [0, 1]");
+  int64_t total, max_len;
+  int rc;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  if ((rc = nw_validate(residues, offsets, n)) != DA_OK) return rc;
+  for (int64_t i = 0; i < n; ++i)
+    if (offsets[i + 1] == offsets[i])
+      return fail(DA_ERR_UNSUPPORTED, "sequence %lld is empty: its similarities are 0/0 = NaN and R's quantile() refuses NaN",
+                  (long long)(i + 1));
+  if (max_len > 127) return fail(DA_ERR_UNSUPPORTED, "the NW edge list works on uint16 codes: sequences up to 127 residues");
+  if ((rc = require_device()) != DA_OK) return rc;
+  DeviceInput in;
+  if ((rc = in.upload(residues, offsets, n, total, nullptr, 0)) != DA_OK) return rc;
+  DevBuf codes, bad, cnt, hist;
+  if ((rc = codes.alloc((size_t)total)) != DA_OK) return rc;
+  if ((rc = bad.alloc(sizeof(int32_t))) != DA_OK) return rc;
+  DA_HIP_TRY(hipMemset(bad.p, 0, sizeof(int32_t)));
+  if ((rc = launch_nw_encode(in.res.as<uint8_t>(), total, codes.as<uint8_t>(), bad.as<int32_t>(), nullptr)) != DA_OK)
+    return rc;
+  if ((rc = cnt.alloc((size_t)n * (size_t)n * 2)) != DA_OK) return rc;      // uint16 codes stay on the device
+  const int nbins = (int)((max_len << 8) | (2 * max_len)) + 1;              // matches <= max_len, length <= 2 * max_len
+  if ((rc = hist.alloc((size_t)nbins * 8)) != DA_OK) return rc;
+  DA_HIP_TRY(hipMemset(hist.p, 0, (size_t)nbins * 8));
+  if ((rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, 0, n, true,
+                      DA_OUT_COMPACT, cnt.p, n, nullptr, 0, nullptr)) != DA_OK) return rc;
+  if ((rc = launch_upper_histogram(cnt.as<uint16_t>(), n, n, nbins, hist.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
+  std::vector<double> values(nbins);
+  for (int b = 0; b < nbins; ++b) {
+    const int ln = b & 255;
+    values[b] = ln ? (double)(b >> 8) / (double)ln : 0.0;                   // length 0 cannot occur (no empty sequences)
+  }
+  return edges_from_counts(cnt.as<uint16_t>(), n, nbins, hist.as<unsigned long long>(), values, thresh_p, threshold_out,
+                           n_edges_out, capacity, ei, ej, ew);
+}
+
 int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
                            const uint32_t *seeds, double thresh_p, double *threshold_out, int64_t *n_edges_out,
                            int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
@@ -519,57 +632,10 @@ int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int6
   if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, DA_OUT_COMPACT, cnt.p, n, nullptr, bits)) != DA_OK)
     return rc;
   if ((rc = launch_upper_histogram(cnt.as<uint16_t>(), n, n, nbins, hist.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
-  std::vector<uint64_t> h(nbins);
-  DA_HIP_TRY(hipMemcpy(h.data(), hist.p, (size_t)nbins * 8, hipMemcpyDeviceToHost));
   std::vector<double> values(nbins);
   for (int b = 0; b < nbins; ++b) values[b] = (double)b / n_hash;          // src/minHash.cpp:174
-  double thr;
-  if ((rc = da_quantile_type7(h.data(), values.data(), nbins, thresh_p, &thr)) != DA_OK) return rc;
-  *threshold_out = thr;
-  // pep.sim[pep.sim < threshold] <- 0 (R/clusterbreak.R:221); a zero weight is no edge (igraph, weighted = TRUE)
-  std::vector<uint8_t> kp(nbins);
-  int64_t n_edges = n;                                                       // the diagonal (1.0) always survives
-  for (int b = 0; b < nbins; ++b) {
-    kp[b] = (b != 0 && !(values[b] < thr)) ? 1 : 0;
-    if (kp[b]) n_edges += (int64_t)h[b];
-  }
-  *n_edges_out = n_edges;
-  if (!ei && !ej && !ew) return DA_OK;                                       // size query
-  if (!ei || !ej || !ew) return fail(DA_ERR_BAD_ARG, "NULL edge buffer");
-  if (capacity < n_edges) return fail(DA_ERR_BAD_ARG, "edge buffers hold %lld entries, %lld needed", (long long)capacity,
-                                      (long long)n_edges);
-  if (n_edges == 0) return DA_OK;
-  DevBuf di, dj, dv;
-  if ((rc = keep.alloc((size_t)nbins)) != DA_OK) return rc;
-  if ((rc = cnt_edges.alloc(8)) != DA_OK) return rc;
-  if ((rc = di.alloc((size_t)n_edges * 4)) != DA_OK) return rc;
-  if ((rc = dj.alloc((size_t)n_edges * 4)) != DA_OK) return rc;
-  if ((rc = dv.alloc((size_t)n_edges * 2)) != DA_OK) return rc;
-  DA_HIP_TRY(hipMemcpy(keep.p, kp.data(), (size_t)nbins, hipMemcpyHostToDevice));
-  DA_HIP_TRY(hipMemset(cnt_edges.p, 0, 8));
-  if ((rc = launch_extract_edges(cnt.as<uint16_t>(), n, n, keep.as<uint8_t>(), nbins, true, di.as<int32_t>(), dj.as<int32_t>(),
-                                 dv.as<uint16_t>(), n_edges, cnt_edges.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
-  uint64_t got = 0;
-  DA_HIP_TRY(hipMemcpy(&got, cnt_edges.p, 8, hipMemcpyDeviceToHost));
-  if ((int64_t)got != n_edges) return fail(DA_ERR_HIP, "edge count mismatch: histogram says %lld, extraction found %llu",
-                                           (long long)n_edges, (unsigned long long)got);
-  std::vector<int32_t> hi_(n_edges), hj_(n_edges);
-  std::vector<uint16_t> hv_(n_edges);
-  DA_HIP_TRY(hipMemcpy(hi_.data(), di.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost));
-  DA_HIP_TRY(hipMemcpy(hj_.data(), dj.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost));
-  DA_HIP_TRY(hipMemcpy(hv_.data(), dv.p, (size_t)n_edges * 2, hipMemcpyDeviceToHost));
-  // the device appends in arrival order; hand the edges back sorted by (i, j)
-  std::vector<int64_t> order(n_edges);
-  for (int64_t e = 0; e < n_edges; ++e) order[e] = e;
-  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-    return hi_[a] != hi_[b] ? hi_[a] < hi_[b] : hj_[a] < hj_[b];
-  });
-  for (int64_t e = 0; e < n_edges; ++e) {
-    ei[e] = hi_[order[e]];
-    ej[e] = hj_[order[e]];
-    ew[e] = values[hv_[order[e]]];
-  }
-  return DA_OK;
+  return edges_from_counts(cnt.as<uint16_t>(), n, nbins, hist.as<unsigned long long>(), values, thresh_p, threshold_out,
+                           n_edges_out, capacity, ei, ej, ew);
 }
 
 int64_t da_sig_ld(int n_hash) { return sig_ld_for(n_hash); }

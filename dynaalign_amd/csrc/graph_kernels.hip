@@ -17,7 +17,7 @@ namespace {
 
 constexpr int G_TILE = 128;
 constexpr int G_THREADS = 256;
-constexpr int G_LDS_BINS = 4096;
+constexpr int G_LDS_BINS = 8192;   // 32 KiB: MH counts (n_hash + 1) and NW codes of peptides up to 31 residues stay in LDS
 
 // upper-triangular 128x128 tile id -> (ti, tj), row-major over the triangle
 __device__ __forceinline__ void tri_tile(int64_t L, int T, int &ti, int &tj) {

@@ -202,3 +202,24 @@ def similarityMH_edges(sequences, k=4, n_hash=50, thresh_p=0.8, *, seed=None):
                                            float(thresh_p), thr.ctypes.data, cnt.ctypes.data, m, ei.ctypes.data,
                                            ej.ctypes.data, ew.ctypes.data))
     return float(thr[0]), ei[:m], ej[:m], ew[:m]
+
+
+def similarityNW_edges(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4, thresh_p=0.8):
+    """similarityNW followed by clusterbreak's threshold step (reference R/clusterbreak.R:217-221), fused on
+    the device like similarityMH_edges: returns ``(threshold, i, j, weight)`` for the surviving entries with
+    i <= j (0-based, sorted).  Sequences up to 127 residues; empty sequences are refused (NaN similarities)."""
+    lib = _capi.load()
+    res, off = pack_sequences(sequences)
+    n = len(off) - 1
+    name = matrixName.encode("latin-1") if isinstance(matrixName, str) else bytes(matrixName)
+    go, ge = _as_int(gapOpen, "gapOpen"), _as_int(gapExt, "gapExt")
+    thr = np.zeros(1, np.float64)
+    cnt = np.zeros(1, np.int64)
+    _capi.check(lib.da_similarity_nw_edges(res.ctypes.data, off.ctypes.data, n, name, go, ge, float(thresh_p),
+                                           thr.ctypes.data, cnt.ctypes.data, 0, None, None, None))
+    m = int(cnt[0])
+    ei, ej, ew = np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.float64)
+    _capi.check(lib.da_similarity_nw_edges(res.ctypes.data, off.ctypes.data, n, name, go, ge, float(thresh_p),
+                                           thr.ctypes.data, cnt.ctypes.data, m, ei.ctypes.data, ej.ctypes.data,
+                                           ew.ctypes.data))
+    return float(thr[0]), ei[:m], ej[:m], ew[:m]

@@ -224,6 +224,14 @@ int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int6
                            int k, int n_hash, const uint32_t *seeds, double thresh_p,
                            double *threshold_out, int64_t *n_edges_out,
                            int64_t capacity, int32_t *ei, int32_t *ej, double *ew);
+/* The same for similarityNW: matches / length takes few distinct values too (the uint16 code
+ * matches << 8 | length), so threshold and edge list come from a histogram of the codes.
+ * Sequences up to 127 residues; an empty sequence is refused (its similarities are NaN and
+ * R's quantile() stops on NaN).  Errors of da_similarity_nw apply unchanged. */
+int da_similarity_nw_edges(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                           const char *matrix_name, int gap_open, int gap_ext, double thresh_p,
+                           double *threshold_out, int64_t *n_edges_out,
+                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew);
 /* R's quantile(x, p, type = 7) of the multiset {values[b] repeated hist[b] times},
  * values ascending (host arithmetic, no device needed). */
 int da_quantile_type7(const uint64_t *hist, const double *values, int nbins, double p, double *q_out);

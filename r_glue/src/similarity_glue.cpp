@@ -137,3 +137,25 @@ List similarityMH_edges(CharacterVector sequences, int k = 4, int n_hash = 50, d
   return List::create(_["threshold"] = thr,
                       _["edges"] = DataFrame::create(_["from"] = from, _["to"] = to, _["weight"] = weight));
 }
+
+//' @name similarityNW_edges
+//' @title Needleman-Wunsch identity + clusterbreak's quantile threshold, as an edge list
+//' @description The similarityNW counterpart of similarityMH_edges (sequences up to 127 residues, none empty).
+//' @export
+// [[Rcpp::export]]
+List similarityNW_edges(CharacterVector sequences, std::string matrixName = "BLOSUM62", int gapOpen = 10,
+                        int gapExt = 4, double thresh_p = 0.8) {
+  const Packed in(sequences);
+  const int64_t n = sequences.length();
+  double thr = 0;
+  int64_t m = 0;
+  check(da_similarity_nw_edges(in.residues.data(), in.offsets.data(), n, matrixName.c_str(), gapOpen, gapExt, thresh_p,
+                               &thr, &m, 0, nullptr, nullptr, nullptr));
+  IntegerVector from(m), to(m);
+  NumericVector weight(m);
+  check(da_similarity_nw_edges(in.residues.data(), in.offsets.data(), n, matrixName.c_str(), gapOpen, gapExt, thresh_p,
+                               &thr, &m, m, INTEGER(from), INTEGER(to), REAL(weight)));
+  for (int64_t e = 0; e < m; ++e) { from[e] += 1; to[e] += 1; }   // R is 1-based
+  return List::create(_["threshold"] = thr,
+                      _["edges"] = DataFrame::create(_["from"] = from, _["to"] = to, _["weight"] = weight));
+}

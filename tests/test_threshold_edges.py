@@ -96,3 +96,41 @@ def test_mh_edges_argument_errors(da):
         da.similarityMH_edges(["ACDEF", "ACDEG"], 4, 50, 1.5, seed=1)
     with pytest.raises(da.DynaAlignError, match="cannot be empty"):
         da.similarityMH_edges([], 4, 50, 0.8, seed=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p,args", [(2, 0.8, ("BLOSUM62", 10, 4)), (130, 0.8, ("BLOSUM62", 10, 4)),
+                                      (641, 0.8, ("BLOSUM62", 10, 4)), (500, 0.5, ("BLOSUM45", 5, 1)),
+                                      (257, 0.0, ("BLOSUM80", 12, 2)), (257, 1.0, ("BLOSUM62", 10, 4)),
+                                      (400, 0.97, ("BLOSUM62", 0, 0))])
+def test_nw_edges_match_dense_threshold(da, evp, n, p, args):
+    """NW ratios take few distinct values too: histogram of (matches, length) codes -> exact type-7 quantile.
+    Different codes with equal ratio (1/2, 2/4) must behave as one value."""
+    from dynaalign_amd import synth
+    seqs = evp if n == 641 else synth.to_strings(*synth.h3n2_like(n, 20))
+    rc, M, _ = O.similarity_nw(seqs, *args)
+    assert rc == 0
+    thr_w, iw, jw, ww = reference_edges(M, p)
+    thr, i, j, w = da.similarityNW_edges(seqs, *args, thresh_p=p)
+    assert thr == thr_w
+    assert np.array_equal(i, iw) and np.array_equal(j, jw)
+    assert np.array_equal(w.view(np.uint64), ww.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_nw_edges_ragged_lengths_and_errors(da):
+    rng = np.random.RandomState(11)
+    alpha = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
+    seqs = ["".join(map(chr, alpha[rng.randint(0, 20, rng.randint(1, 60))])) for _ in range(220)]
+    rc, M, _ = O.similarity_nw(seqs, "BLOSUM62", 10, 4)
+    thr_w, iw, jw, ww = reference_edges(M, 0.9)
+    thr, i, j, w = da.similarityNW_edges(seqs, thresh_p=0.9)
+    assert thr == thr_w and np.array_equal(i, iw) and np.array_equal(j, jw) and np.array_equal(w, ww)
+    with pytest.raises(da.DynaAlignError, match="empty"):
+        da.similarityNW_edges(["ACD", "", "ACE"])
+    with pytest.raises(da.DynaAlignError, match="Invalid substitution matrix name"):
+        da.similarityNW_edges(["ACD", "ACE"], "PAM250")
+    with pytest.raises(da.DynaAlignError, match="Invalid amino acid"):
+        da.similarityNW_edges(["ACD", "AJE"])
+    with pytest.raises(da.DynaAlignError):
+        da.similarityNW_edges(["ACD"])
