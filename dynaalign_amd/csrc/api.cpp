@@ -611,7 +611,7 @@ int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int6
   DeviceInput in;
   if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
   const int64_t lds = sig_ld_for(n_hash);
-  DevBuf sig, planes, cnt, hist, keep, cnt_edges;
+  DevBuf sig, planes, cnt, hist;
   if ((rc = sig.alloc((size_t)n * lds * 4)) != DA_OK) return rc;
   if ((rc = planes.alloc((size_t)mh_planes_words(n, n_hash) * 4)) != DA_OK) return rc;
   if ((rc = cnt.alloc((size_t)n * (size_t)n * 2)) != DA_OK) return rc;   // uint16 counts stay on the device
