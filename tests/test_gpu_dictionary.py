@@ -163,3 +163,62 @@ def test_worst_case_id_count(da):
     ds3 = device.DeviceSequences(res3, off3)
     _, p = device.minhash_signatures(ds3, 8, n_hash, seeds)
     assert p.bits == 32
+
+
+def _unmix(z):
+    """inverse of the dictionary's key mixer (murmur3's 32-bit finaliser)"""
+    z = int(z)
+    z ^= z >> 16
+    z = (z * 0x7ED1B41D) & 0xFFFFFFFF          # inverse of 0xc2b2ae35 mod 2^32
+    z ^= (z >> 13) ^ (z >> 26)
+    z = (z * 0xA5CB9243) & 0xFFFFFFFF          # inverse of 0x85ebca6b mod 2^32
+    z ^= z >> 16
+    return z
+
+
+def _mix(x):
+    x = int(x)
+    x ^= x >> 16
+    x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+    x ^= x >> 13
+    x = (x * 0xC2B2AE35) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+@pytest.mark.parametrize("n", [2, 8191, 8192, 8193, 16385, 30000])
+def test_crafted_signature_columns(da, n):
+    """signature matrices written directly (no hashing), one pathology per column: all equal, all distinct,
+    two values, 0 / 0xFFFFFFFF, the keys whose mixed value is the LDS table's empty marker of each
+    partition (they live in another partition, so they must still be found), heavy duplicates."""
+    import torch
+    from dynaalign_amd import device, _capi
+    assert all(_mix(_unmix(z)) == z for z in (0, 1, 0x12345678, 0xFFFFFFFF, 0x80000000))
+    rng = np.random.RandomState(n)
+    R = max(2, -(-n // 8192))
+    empties = [(((q << 32) + R - 1) // R) for q in range(R)]          # smallest mixed key of partition q
+    special = np.array([_unmix(z) for z in empties] + [0, 0xFFFFFFFF, 1, 0x80000000], np.uint64)
+    cols = [np.full(n, 7, np.uint64),
+            rng.permutation(n).astype(np.uint64) * 40503 % (1 << 32),
+            rng.randint(0, 2, n).astype(np.uint64) * 0xFFFFFFFF,
+            special[rng.randint(0, len(special), n)],
+            np.where(rng.rand(n) < 0.5, special[rng.randint(0, len(special), n)], rng.randint(0, 1 << 32, n).astype(np.uint64)),
+            rng.randint(0, max(2, n // 3), n).astype(np.uint64),
+            rng.randint(0, 1 << 32, n).astype(np.uint64)]
+    n_hash = 70                                                         # 3 groups, the last one partial
+    sig_h = np.stack([cols[h % len(cols)] if h < 2 * len(cols) else rng.randint(0, 50, n).astype(np.uint64)
+                      for h in range(n_hash)], 1).astype(np.uint32)
+    sig = torch.zeros((n, device.sig_ld(n_hash)), dtype=torch.int32, device="cuda")
+    sig[:, :n_hash] = torch.from_numpy(sig_h.view(np.int32)).cuda()
+    pc = device.mh_planes(sig, n, n_hash)
+    p32 = device.mh_planes(sig, n, n_hash, min_plane_bits=32)
+    assert pc.bits == _bits_needed(sig_h) and p32.bits == 32
+    rows = (0, min(n, 140)) if n > 3000 else (0, n)
+    want = np.stack([(sig_h[i][None, :] == sig_h).sum(1) for i in range(*rows)]).astype(np.uint16)
+    for p in (pc, p32):
+        got = device.mh_compare(p, n, n_hash, rows[0], rows[1], rows == (0, n), _capi.DA_OUT_COMPACT)
+        assert np.array_equal(got.cpu().numpy().view(np.uint16), want)
+    if n > 3000:                                                        # whole matrix: both operands agree everywhere
+        a = device.mh_compare(pc, n, n_hash, kind=_capi.DA_OUT_COMPACT)
+        b = device.mh_compare(p32, n, n_hash, kind=_capi.DA_OUT_COMPACT)
+        assert torch.equal(a, b)
