@@ -192,7 +192,7 @@ def main():
         phase_names = ["k1_signatures", "k1b_codes_to_planes", "k2_compare"]
     else:
         plan = sharding.Plan(n, rank, world, sharding.MH_TILE)
-        work = sharding.Workspace(plan, "cuda")
+        work = sharding.PackedWorkspace(plan, n_hash, "cuda")   # counts travel in bits(n_hash) = 9 bits, not 16
 
         def step():
             e = [ev() for _ in range(6)]
@@ -200,10 +200,11 @@ def main():
             pl = signatures_and_planes(e[1])                      # every rank: all signatures (2 MB in)
             e[2].record()
             sharding.mh_local_block(plan, work, pl, n_hash)
+            sharding.pack_local_block(plan, work)
             e[3].record()
-            sharding.all_pairs_sharded(plan, work.local, work.gathered, lambda gathered: gathered)
+            sharding.all_pairs_sharded(plan, work.packed, work.gathered, lambda gathered: gathered)
             e[4].record()
-            sharding.finalize_shards(plan, work.gathered, False, n_hash, out)
+            sharding.finalize_shards_packed(plan, work, work.gathered, n_hash, out)
             e[5].record()
             return e
         phase_names = ["k1_signatures", "k1b_codes_to_planes", "k2_compare_shard", "all_gather", "finalize"]
@@ -261,7 +262,7 @@ def main():
                                % (n, "h3n2-like" if a.workload == "h3n2like" else "uniform"),
                    "n": n, "k": k, "n_hash": n_hash, "pairs": pairs_mh,
                    "sharding": "1 GPU: upper-triangle tiles + mirrored store" if world == 1
-                   else "cyclic tile rows over %d ranks, one RCCL all-gather of uint16 counts, mirror+widen on every rank" % world},
+                   else "cyclic tile rows over %d ranks, one RCCL all-gather of the 9-bit packed counts, mirror+widen on every rank" % world},
         "roofline": roof,
         "phases_ms": phases,
     }

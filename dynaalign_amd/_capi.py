@@ -52,6 +52,9 @@ SIGNATURES = {
     "da_matrix_id": (_i32, [C.c_char_p]),
     "da_shard_rows": (_i64, [_i64, _i32, _i32]),
     "da_shard_ld": (_i64, [_i64, _i32, _i32]),
+    "da_shard_packed_bytes": (_i64, [_i64, _i32, _i32]),
+    "da_dev_pack_shard": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "da_dev_finalize_shards_packed": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_mh_compare_shard": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_shard": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_finalize_shards": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),

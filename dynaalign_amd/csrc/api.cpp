@@ -388,6 +388,35 @@ int da_dev_mh_compare_shard(const uint32_t *d_planes, int plane_bits, int64_t n,
                            static_cast<hipStream_t>(stream), plane_bits, world, true, sg.Q, sg.W);
 }
 
+// ---- the MH exchange in value_bits = bits(n_hash) instead of 16 bits per count
+static int packed_args_ok(int64_t n, int world, int value_bits) {
+  if (n <= 0 || world <= 0) return fail(DA_ERR_BAD_ARG, "bad shard arguments");
+  if (value_bits < 1 || value_bits > 16) return fail(DA_ERR_BAD_ARG, "value_bits must be in [1, 16] (got %d)", value_bits);
+  return DA_OK;
+}
+int64_t da_shard_packed_bytes(int64_t n, int world, int value_bits) {
+  if (n <= 0 || world <= 0 || value_bits < 1 || value_bits > 16) return 0;
+  return shard_packed_bytes(shard_geom(n, world, 128), value_bits);
+}
+int da_dev_pack_shard(const uint16_t *d_local, int64_t ld, int64_t n, int world, int value_bits, uint8_t *d_packed,
+                      void *stream) {
+  int rc = packed_args_ok(n, world, value_bits);
+  if (rc != DA_OK) return rc;
+  const ShardGeom sg = shard_geom(n, world, 128);
+  if (!d_local || !d_packed || ld < sg.W) return fail(DA_ERR_BAD_ARG, "bad block / ld");
+  if (reinterpret_cast<uintptr_t>(d_packed) & 7) return fail(DA_ERR_BAD_ARG, "packed block must be 8-byte aligned");
+  return launch_pack_shard(d_local, ld, sg, value_bits, d_packed, static_cast<hipStream_t>(stream));
+}
+int da_dev_finalize_shards_packed(const uint8_t *d_gathered, int64_t n, int world, int value_bits, int n_hash,
+                                  double *d_out, int64_t ld_out, void *stream) {
+  int rc = packed_args_ok(n, world, value_bits);
+  if (rc != DA_OK) return rc;
+  if (!d_gathered || !d_out || ld_out < n) return fail(DA_ERR_BAD_ARG, "bad arguments");
+  if (n_hash <= 0 || n_hash >= (1 << value_bits)) return fail(DA_ERR_BAD_ARG, "n_hash (%d) does not fit value_bits (%d)", n_hash, value_bits);
+  return launch_finalize_packed(d_gathered, shard_geom(n, world, 128), value_bits, n_hash, d_out, ld_out,
+                                static_cast<hipStream_t>(stream));
+}
+
 int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len, int matrix_id,
                     int gap_open, int gap_ext, int rank, int world, uint16_t *d_local, int64_t ld, void *stream) {
   if (n <= 0) return DA_OK;

@@ -108,6 +108,11 @@ int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n
                          hipStream_t stream);
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
                             double *d_out, int64_t ld, hipStream_t stream);
+int64_t shard_packed_bytes(const ShardGeom &g, int value_bits);
+int launch_pack_shard(const uint16_t *d_local, int64_t ld, const ShardGeom &geom, int value_bits, uint8_t *d_packed,
+                      hipStream_t stream);
+int launch_finalize_packed(const uint8_t *d_g, const ShardGeom &geom, int value_bits, int n_hash, double *d_out, int64_t ld,
+                           hipStream_t stream);
 int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,
                      hipStream_t stream);
 int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,

@@ -808,6 +808,121 @@ int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &
   return DA_OK;
 }
 
+// ---- b-bit packing of the MH shard blocks for the exchange -------------------------------------
+// A match count needs value_bits = bits(n_hash) <= 16 bits (9 at n_hash = 500), the gather is what
+// the multi-GPU MH step waits for, so a rank's uint16 block [rows][W] travels as a byte plane
+// (low 8 bits) followed by value_bits - 8 bit planes ([rows][W/8] bytes each, bit c&7 of byte c>>3).
+__global__ __launch_bounds__(256) void k_pack_shard(const uint16_t *__restrict__ local, int64_t ld, int64_t rows, int64_t W,
+                                                    int nhi, uint8_t *__restrict__ packed) {
+  const int64_t groups = W >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * groups) return;
+  const int64_t row = idx / groups, g = idx - row * groups;
+  const uint16_t *src = local + row * ld + 8 * g;
+  uint32_t v[8];
+  if (((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(local) & 15) == 0)) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(src);
+    v[0] = q.x & 0xffffu; v[1] = q.x >> 16; v[2] = q.y & 0xffffu; v[3] = q.y >> 16;
+    v[4] = q.z & 0xffffu; v[5] = q.z >> 16; v[6] = q.w & 0xffffu; v[7] = q.w >> 16;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[e];
+  }
+  uint2 lo;
+  lo.x = (v[0] & 255u) | ((v[1] & 255u) << 8) | ((v[2] & 255u) << 16) | ((v[3] & 255u) << 24);
+  lo.y = (v[4] & 255u) | ((v[5] & 255u) << 8) | ((v[6] & 255u) << 16) | ((v[7] & 255u) << 24);
+  *reinterpret_cast<uint2 *>(packed + row * W + 8 * g) = lo;
+  uint8_t *hi = packed + rows * W;
+  for (int k = 0; k < nhi; ++k) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b |= ((v[e] >> (8 + k)) & 1u) << e;
+    hi[((int64_t)k * rows + row) * groups + g] = (uint8_t)b;
+  }
+}
+
+// k_finalize_sharded reading packed blocks (MH only): G = world blocks of block_bytes each
+__global__ __launch_bounds__(256) void k_finalize_packed(const uint8_t *__restrict__ G, int64_t block_bytes, ShardGeom geom,
+                                                         int nhi, int n_hash, double *__restrict__ out, int64_t ld, int TB,
+                                                         int64_t ntiles, int64_t per_xcd) {
+  constexpr int FT = 64, TABLE = 2048;
+  __shared__ uint16_t t[FT][FT + 2];
+  __shared__ double ratio[TABLE];
+  const int n = (int)geom.n;
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= ntiles) return;
+  const TileId tt = decode_tile(L, TB, TB, true);
+  if (!tt.valid) return;
+  const int i0 = tt.ti * FT, j0 = tt.tj * FT;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const bool use_table = n_hash < TABLE;
+  if (use_table)
+    for (int c = threadIdx.x; c <= n_hash; c += 256) ratio[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
+  auto widen = [&](uint32_t v) -> double { return use_table ? ratio[v] : (double)v / (double)n_hash; };
+  const int tile = geom.tile;
+  const int tr = i0 / tile;
+  const int q = tr / geom.world, owner = tr - q * geom.world;
+  const bool front = q <= geom.Q - 1 - q;
+  const int64_t lrow0 = (int64_t)(front ? q : geom.Q - 1 - q) * tile + (i0 - tr * tile);   // row inside the owner's block
+  const int64_t coff = front ? -(int64_t)tr * tile : geom.W - geom.n;
+  const uint8_t *blk = G + (int64_t)owner * block_bytes;
+  const int64_t W = geom.W, groups = W >> 3, rows = geom.rows;
+  const int j = j0 + tx;
+  const int64_t col = coff + j;
+  for (int r = ty; r < FT; r += 4) {
+    const int i = i0 + r;
+    if (i < n && j < n && j >= i) {
+      const int64_t row = lrow0 + r;
+      uint32_t v = blk[row * W + col];
+      for (int k = 0; k < nhi; ++k)
+        v |= (uint32_t)((blk[rows * W + ((int64_t)k * rows + row) * groups + (col >> 3)] >> (col & 7)) & 1u) << (8 + k);
+      t[r][tx] = (uint16_t)v;
+    }
+  }
+  __syncthreads();
+  double *o = out + (int64_t)i0 * ld + j;
+  for (int r = ty; r < FT; r += 4) {
+    const int i = i0 + r;
+    if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part as computed
+  }
+  const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
+  double *om = out + (int64_t)j0 * ld + im;
+  for (int r = ty; r < FT; r += 4) {
+    const int jm = j0 + r;
+    if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
+  }
+}
+
+int64_t shard_packed_bytes(const ShardGeom &g, int value_bits) {
+  const int nhi = value_bits > 8 ? value_bits - 8 : 0;
+  return g.rows * g.W + (int64_t)nhi * g.rows * (g.W >> 3);
+}
+
+int launch_pack_shard(const uint16_t *d_local, int64_t ld, const ShardGeom &geom, int value_bits, uint8_t *d_packed,
+                      hipStream_t stream) {
+  if (geom.n <= 0) return DA_OK;
+  const int nhi = value_bits > 8 ? value_bits - 8 : 0;
+  const int64_t work = geom.rows * (geom.W >> 3);
+  hipLaunchKernelGGL(k_pack_shard, dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, stream, d_local, ld, geom.rows, geom.W,
+                     nhi, d_packed);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+int launch_finalize_packed(const uint8_t *d_g, const ShardGeom &geom, int value_bits, int n_hash, double *d_out, int64_t ld,
+                           hipStream_t stream) {
+  if (geom.n <= 0) return DA_OK;
+  if (geom.n > 0x7fffffffLL || (geom.tile % 64) != 0) return fail(DA_ERR_UNSUPPORTED, "finalize: unsupported geometry");
+  const int TB = (int)ceil_div(geom.n, 64);
+  const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
+  if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
+  const int64_t per_xcd = ceil_div(tiles, 8);
+  hipLaunchKernelGGL(k_finalize_packed, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, stream, d_g, shard_packed_bytes(geom, value_bits),
+                     geom, value_bits > 8 ? value_bits - 8 : 0, n_hash, d_out, ld, TB, tiles, per_xcd);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
 int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream) {
   if (n <= 1) return DA_OK;
   const unsigned t = (unsigned)ceil_div(n, 32);

@@ -127,6 +127,43 @@ def mh_sharded_step(plan, work, planes, n_hash, out, group=None):
                              lambda g: finalize_shards(plan, g, False, n_hash, out), group)
 
 
+def value_bits(n_hash):
+    """bits a match count needs (at least the byte plane)"""
+    return max(8, int(n_hash).bit_length())
+
+
+class PackedWorkspace(Workspace):
+    """Workspace whose exchange buffers hold the MH counts in value_bits(n_hash) bits instead of 16:
+    a byte plane + bit planes per rank block (da_dev_pack_shard)."""
+
+    def __init__(self, plan, n_hash, device="cuda"):
+        self.local = torch.zeros((plan.local_rows, plan.width), dtype=torch.int16, device=device)
+        self.bits = value_bits(n_hash)
+        self.block_bytes = int(_capi.load().da_shard_packed_bytes(plan.n, plan.world, self.bits))
+        self.packed = torch.empty(self.block_bytes, dtype=torch.uint8, device=device)
+        self.gathered = torch.empty(plan.world * self.block_bytes, dtype=torch.uint8, device=device)
+
+
+def pack_local_block(plan, work):
+    _capi.check(_capi.load().da_dev_pack_shard(work.local.data_ptr(), work.local.stride(0), plan.n, plan.world, work.bits,
+                                               work.packed.data_ptr(), _stream()))
+    return work.packed
+
+
+def finalize_shards_packed(plan, work, gathered, n_hash, out):
+    _capi.check(_capi.load().da_dev_finalize_shards_packed(gathered.data_ptr(), plan.n, plan.world, work.bits, int(n_hash),
+                                                           out.data_ptr(), out.stride(0), _stream()))
+    return out
+
+
+def mh_sharded_step_packed(plan, work, planes, n_hash, out, group=None):
+    """mh_sharded_step with the exchange in value_bits(n_hash) bits per count (work: PackedWorkspace)"""
+    mh_local_block(plan, work, planes, n_hash)
+    pack_local_block(plan, work)
+    return all_pairs_sharded(plan, work.packed, work.gathered,
+                             lambda g: finalize_shards_packed(plan, work, g, n_hash, out), group)
+
+
 def nw_local_block(plan, work, ds, matrix_name="BLOSUM62", gap_open=10, gap_ext=4):
     assert plan.tile == NW_TILE
     lib = _capi.load()

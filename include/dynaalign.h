@@ -210,6 +210,17 @@ int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n,
 int da_dev_finalize_shards(const uint16_t *d_gathered, int64_t ld_g, int64_t n, int world,
                            int is_nw, int n_hash, double *d_out, int64_t ld_out, void *stream);
 
+/* The MH exchange in value_bits = bits(n_hash) <= 16 bits per count instead of 16 (9 at n_hash = 500;
+ * the all-gather is what the multi-GPU MH step waits for): da_dev_pack_shard turns a rank's uint16
+ * block into a byte plane (low 8 bits) + value_bits - 8 bit planes, da_shard_packed_bytes() bytes in
+ * all, 8-byte aligned; one all-gather of those; da_dev_finalize_shards_packed expands the gathered
+ * world * da_shard_packed_bytes() bytes to the dense float64 matrix like da_dev_finalize_shards. */
+int64_t da_shard_packed_bytes(int64_t n, int world, int value_bits);
+int da_dev_pack_shard(const uint16_t *d_local, int64_t ld, int64_t n, int world, int value_bits,
+                      uint8_t *d_packed, void *stream);
+int da_dev_finalize_shards_packed(const uint8_t *d_gathered, int64_t n, int world, int value_bits,
+                                  int n_hash, double *d_out, int64_t ld_out, void *stream);
+
 /* ---- threshold + sparsify: what clusterbreak does right after sim_fn ---------
  * reference R/clusterbreak.R:219-221 (+ netcluster's graph_from_adjacency_matrix
  * mode = "upper", :122-124):

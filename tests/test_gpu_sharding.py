@@ -138,3 +138,34 @@ def test_symmetrize_and_widen_helpers(da):
         device.symmetrize(g, n, _capi.DA_OUT_F64)
         fw = f.cpu().numpy()
         assert np.array_equal(g.cpu().numpy(), np.triu(fw) + np.triu(fw, 1).T)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("n,n_hash", [(129, 500), (700, 500), (700, 200), (300, 1000)])
+def test_mh_packed_exchange_virtual_ranks(da, world, n, n_hash):
+    """the MH exchange in bits(n_hash) bits per count: every rank's block packed by the HIP kernel, the
+    concatenation (= what the all-gather delivers) expanded by the packed finalize kernel == the oracle"""
+    from dynaalign_amd import device, sharding, synth
+    res, off = synth.h3n2_like(n, 20)
+    seqs = synth.to_strings(res, off)
+    seeds = da.hash_family_seeds(12345, n_hash)
+    ds = device.DeviceSequences(res, off)
+    sig, planes = device.minhash_signatures(ds, 4, n_hash, seeds)
+    blocks = []
+    for r in range(world):
+        plan = sharding.Plan(n, r, world, sharding.MH_TILE)
+        work = sharding.PackedWorkspace(plan, n_hash)
+        assert work.bits == (8 if n_hash < 256 else 9 if n_hash < 512 else 10)
+        work.local.fill_(0x7FFF)
+        sharding.mh_local_block(plan, work, planes, n_hash)
+        blocks.append(sharding.pack_local_block(plan, work).clone())
+    gathered = torch.cat(blocks)
+    assert gathered.numel() == world * work.block_bytes < world * plan.local_rows * plan.width * 2
+    out = torch.full((n, n), -1.0, dtype=torch.float64, device="cuda")
+    sharding.finalize_shards_packed(plan, work, gathered, n_hash, out)
+    rc, want = O.similarity_mh(seqs, 4, n_hash, seeds)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    if world == 1:
+        out2 = torch.empty_like(out)
+        sharding.mh_sharded_step_packed(plan, work, planes, n_hash, out2)
+        assert torch.equal(out, out2)

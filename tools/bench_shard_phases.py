@@ -32,6 +32,13 @@ def main():
                                "finalize_ms": t_ms(lambda: sharding.finalize_shards(plan, work.gathered, False, n_hash, out)),
                                "block_GB": work.local.numel() * 2 / 1e9, "gathered_GB": work.gathered.numel() * 2 / 1e9}
         del work
+        pwork = sharding.PackedWorkspace(plan, n_hash)
+        sharding.mh_local_block(plan, pwork, planes, n_hash)
+        pwork.gathered.zero_()
+        r["mh_w%d" % world].update({"pack_ms": t_ms(lambda: sharding.pack_local_block(plan, pwork)),
+                                    "finalize_packed_ms": t_ms(lambda: sharding.finalize_shards_packed(plan, pwork, pwork.gathered, n_hash, out)),
+                                    "packed_block_GB": pwork.block_bytes / 1e9, "value_bits": pwork.bits})
+        del pwork
         nplan = sharding.Plan(n, 0, world, sharding.NW_TILE)
         nwork = sharding.Workspace(nplan)
         r["nw_w%d" % world] = {"shard_ms_rank0": t_ms(lambda: sharding.nw_local_block(nplan, nwork, ds), 1),
