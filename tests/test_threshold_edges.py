@@ -134,3 +134,27 @@ def test_nw_edges_ragged_lengths_and_errors(da):
         da.similarityNW_edges(["ACD", "AJE"])
     with pytest.raises(da.DynaAlignError):
         da.similarityNW_edges(["ACD"])
+
+
+@pytest.mark.gpu
+def test_session_subsets_equal_fresh_calls(da):
+    """signatures stay in HBM; a recursion level on an index subset gives exactly what a
+    fresh similarityMH / similarityMH_edges call on those sequences gives under the same seed"""
+    from dynaalign_amd import synth
+    from dynaalign_amd.session import MinHashSession
+    seqs = synth.to_strings(*synth.h3n2_like(1500, 20))
+    s = MinHashSession(seqs, 4, 200, seed=777)
+    rng = np.random.RandomState(0)
+    full = np.asarray(da.similarityMH(seqs, 4, 200, seed=777))
+    assert np.array_equal(np.asarray(s.similarity()).view(np.uint64), full.view(np.uint64))
+    for m in (2, 129, 640):
+        idx = rng.permutation(1500)[:m]
+        sub = [seqs[i] for i in idx]
+        want = np.asarray(da.similarityMH(sub, 4, 200, seed=777))
+        assert np.array_equal(np.asarray(s.similarity(idx)).view(np.uint64), want.view(np.uint64))
+        assert np.array_equal(want, full[np.ix_(idx, idx)])                  # and it is the sub-block of the full matrix
+        thr_w, iw, jw, ww = da.similarityMH_edges(sub, 4, 200, 0.8, seed=777)
+        thr, i, j, w = s.edges(idx, 0.8)
+        assert thr == thr_w and np.array_equal(i, iw) and np.array_equal(j, jw) and np.array_equal(w, ww)
+    with pytest.raises(da.DynaAlignError):
+        s.similarity([])
