@@ -114,7 +114,9 @@ struct DeviceInput {
 // (hipHostRegister of the destination would pin up to 80 GB of R's heap -- not ours to pin.)
 int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
   constexpr size_t CHUNK = (size_t)64 << 20;
-  constexpr int RING = 4, WORKERS = 4;
+  constexpr int RING = 4, MAX_WORKERS = 32;
+  int WORKERS = 8;                       // host threads per chunk (first-touch page faults of the destination parallelise)
+  if (const char *e = getenv("DYNAALIGN_D2H_THREADS")) WORKERS = std::max(1, std::min(MAX_WORKERS, atoi(e)));
   if (bytes <= CHUNK || getenv("DYNAALIGN_PLAIN_D2H")) {
     DA_HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return DA_OK;
@@ -141,12 +143,12 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
     const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
     const char *src = static_cast<const char *>(ring[c % RING].pin);
     char *d = static_cast<char *>(dst) + off;
-    std::thread th[WORKERS - 1];
+    std::thread th[MAX_WORKERS];
     const size_t part = (len + WORKERS - 1) / WORKERS;
     for (int w = 1; w < WORKERS; ++w)
       th[w - 1] = std::thread([=]() { const size_t b = w * part; if (b < len) memcpy(d + b, src + b, std::min(part, len - b)); });
     memcpy(d, src, std::min(part, len));
-    for (auto &t : th) t.join();
+    for (int w = 1; w < WORKERS; ++w) th[w - 1].join();
   };
   for (size_t c = 0; c < nchunk + RING - 1 && rc == DA_OK; ++c) {
     if (c < nchunk) {                  // slot c % RING was drained RING iterations ago
