@@ -72,5 +72,8 @@ int main() {
   run("256 thr, 8x4/lane, barrier, 4 blocks/CU", k<256, 4, 4, true>, 256, 4, 4, out);
   run("256 thr, 8x4/lane, barrier, 3 blocks/CU", k<256, 4, 4, true>, 256, 4, 3, out);
   run("512 thr, 8x8/lane (256 VGPR budget), 1 block/CU", k<512, 8, 2, true>, 512, 8, 1, out);
+  run("256 thr, 8x16/lane (256 VGPR budget), 2 blocks/CU", k<256, 16, 2, true>, 256, 16, 2, out);
+  run("256 thr, 8x12/lane (256 VGPR budget), 2 blocks/CU", k<256, 12, 2, true>, 256, 12, 2, out);
+  run("256 thr, 8x8/lane, 2 blocks/CU (occupancy only)", k<256, 8, 2, true>, 256, 8, 2, out);
   return 0;
 }
