@@ -50,6 +50,52 @@ __global__ __launch_bounds__(THREADS, MINW) void k(unsigned *out, int iters) {
   out[blockIdx.x * THREADS + tid] = acc;
 }
 
+// 2-plane steps: operands read as 8 bytes (a: 16 registers instead of 32) so that 8x8 pairs per lane fit 128 VGPRs
+// and 4 workgroups of 256 threads (4 waves per SIMD) are resident
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k64(unsigned *out, int iters) {
+  __shared__ __attribute__((aligned(16))) uint4 lds[3 * 768];   // 36 KiB ring (12-plane stages)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 3 * 768; i += 256) lds[i] = make_uint4(i * 2654435761u, i ^ 0x1234567, i * 40503u, ~i);
+  __syncthreads();
+  const int tx = (wave & 1) * 8 + (lane & 7), ty = (wave >> 1) * 8 + (lane >> 3);
+  const int base_a = ty * 3, base_b = 384 + tx * 3;
+  unsigned d[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[r][c] = 0;
+  for (int it = 0; it < iters; ++it) {
+    const uint2 *S = reinterpret_cast<const uint2 *>(lds + (it % 3) * 768);
+    __syncthreads();
+#pragma unroll 1
+    for (int hs = 0; hs < 6; ++hs) {          // 6 half-segments of 2 planes = 12 planes
+      const uint2 *Sa = S + 2 * base_a + hs;
+      const uint2 *Sb = S + 2 * base_b + hs;
+      uint2 a[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) a[r] = Sa[r * 96];
+      uint2 b = Sb[0];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint2 bn = (c + 1 < 8) ? Sb[(c + 1) * 96] : b;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          unsigned v = or_xor(d[r][c], a[r].x, b.y);
+          d[r][c] = or_xor(v, a[r].y, b.x);
+        }
+        b = bn;
+      }
+    }
+  }
+  unsigned acc = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc += d[r][c];
+  out[blockIdx.x * 256 + tid] = acc;
+}
+
 template <typename K>
 void run(const char *name, K kern, int threads, int nc, int blocks_per_cu, unsigned *out) {
   const int iters = 2000, blocks = 256 * blocks_per_cu;
@@ -60,7 +106,7 @@ void run(const char *name, K kern, int threads, int nc, int blocks_per_cu, unsig
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, iters);
   CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-  double ops = (double)blocks * threads * iters * 4 * 8 * nc * 4;
+  double ops = (double)blocks * threads * iters * (nc < 0 ? 6 * 8 * 8 * 2 : 4 * 8 * nc * 4);
   printf("%-52s blocks/CU=%d  %8.2f ms  %7.1f T lane-bitop3/s\n", name, blocks_per_cu, ms, ops / (ms * 1e-3) / 1e12);
 }
 
@@ -75,5 +121,8 @@ int main() {
   run("256 thr, 8x16/lane (256 VGPR budget), 2 blocks/CU", k<256, 16, 2, true>, 256, 16, 2, out);
   run("256 thr, 8x12/lane (256 VGPR budget), 2 blocks/CU", k<256, 12, 2, true>, 256, 12, 2, out);
   run("256 thr, 8x8/lane, 2 blocks/CU (occupancy only)", k<256, 8, 2, true>, 256, 8, 2, out);
+  run("256 thr, 8x8/lane, b64 operands, 12-plane stages, 4 blocks/CU", k64<4>, 256, -1, 4, out);
+  run("256 thr, 8x8/lane, b64 operands, 12-plane stages, 3 blocks/CU", k64<3>, 256, -1, 3, out);
+  run("256 thr, 8x8/lane, b64 operands, 12-plane stages, 2 blocks/CU", k64<2>, 256, -1, 2, out);
   return 0;
 }
