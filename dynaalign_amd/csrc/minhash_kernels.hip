@@ -738,7 +738,8 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
 // workgroups are 4 KiB of one output row and the direct pieces of a band's next column follow on
 // (row-major tile order: 23.5 ms, this order: 21 ms at N = 100k; a 128 x 128 variant with the
 // compare kernel's 16-byte store pattern and 140 VGPRs ran 30 ms -- too few waves to hide the
-// read -> LDS -> store chain).  64 divides the shard tile (128 / 64), so which rank's block and
+// read -> LDS -> store chain; a low-register 128 x 128 variant whose wave-wide stores cover 1 KiB
+// row pieces: 26.7 ms; persistent workgroups: 23.6 ms).  64 divides the shard tile (128 / 64), so which rank's block and
 // which folded row a tile reads from is workgroup-uniform integer arithmetic.  MH widens through
 // an LDS table built with the reference's divide.
 template <bool IS_NW>
