@@ -257,6 +257,134 @@ __device__ unsigned long long *g_k2_timing = nullptr;   // [blocks][8]: t_entry,
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
+#ifdef DA_K2_DEBUG
+__device__ uint32_t *g_k2_debug = nullptr;
+#endif
+// Which tiles the hand-scheduled kernel below computes: strictly above the diagonal, wholly inside the matrix,
+// output aligned for its wide stores.  Everything else stays with k_mh_compare (only_edge = 1).
+__device__ __forceinline__ bool a12_takes(int ti, int tj, int64_t n, int64_t ld, const void *out, bool f64) {
+  return ti != tj && (int64_t)(ti + 1) * K2_TILE <= n && (int64_t)(tj + 1) * K2_TILE <= n && (ld & 1) == 0 &&
+         (reinterpret_cast<uintptr_t>(out) & (f64 ? 15 : 3)) == 0;
+}
+
+// ---- 12-plane compare with a hand-allocated stage loop ------------------------------------------
+// hipcc needs ~30 VGPRs more than the loop strictly does, which pins k_mh_compare at 168 VGPRs = 3 waves per SIMD
+// -- an odd wave count, which costs the gfx950 VALU a quarter of its issue slots (tools/ubench/k2_inner2).  Here the
+// stage loop (DMA issue, counted waits, barriers, plane loop with 8-byte operands, popcounts) is ONE asm statement
+// with a fixed register map (tools/gen_k2_asm.py -> k2_loop_p12.inc): 116 + 10 VGPRs, so 4 workgroups per CU =
+// 4 waves per SIMD.  The C++ around it decodes the tile, hands five per-lane values over in v120..v124, reads the
+// 32 packed mismatch counters back from LDS and stores the tile like k_mh_compare's straight-line epilogue.
+// Symmetric mode, interior off-diagonal tiles only (a12_takes).
+template <bool F64>
+__global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
+                                                                  void *__restrict__ out_v, int64_t ld, int64_t ntiles,
+                                                                  int64_t per_xcd) {
+  constexpr int PL = 12, SEGS = 3, STAGE_UNITS = 2 * K2_TILE * SEGS;
+  __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring; afterwards counters, then the ratio table
+  const int64_t bid = blockIdx.x;
+  const int T = (int)((n + K2_TILE - 1) / K2_TILE);
+  const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
+  if (L >= ntiles) return;
+  const TileId tl = decode_tile(L, T, T, true);
+  if (!tl.valid || !a12_takes(tl.ti, tl.tj, n, ld, out_v, F64)) return;
+  const int64_t I0 = (int64_t)tl.ti * K2_TILE, J0 = (int64_t)tl.tj * K2_TILE;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tx = ((wave & 1) << 3) + (lane & 7), ty = ((wave >> 1) << 3) + (lane >> 3);
+  const PlaneGeom pg = plane_geom(n, n_hash, PL);
+  // DMA source of this lane in the wave's first instruction of stage 0; instructions q = 1, 2 read 1 KiB and 2 KiB
+  // further (the operand is stored in staging order), stage s reads 128 * 12 words further
+  const int u = wave * SEGS * 64 + lane, sl0 = u / SEGS, sl = sl0 & 127;
+  const uint32_t *src = planes + (sl0 < 128 ? 0 : pg.copy_words) +
+                        plane_unit_word(pg, (sl0 < 128 ? I0 : J0) + k2_row_of_slot(sl), 0, u - sl0 * SEGS);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)lds_ab);
+  const uint32_t a_off = lds_base + (uint32_t)(ty * SEGS * 16);
+  const uint32_t b_off = lds_base + (uint32_t)((K2_TILE * SEGS + tx * SEGS) * 16);
+  const uint32_t src_lo = (uint32_t)reinterpret_cast<uintptr_t>(src), src_hi = (uint32_t)(reinterpret_cast<uintptr_t>(src) >> 32);
+  const uint32_t wb = (uint32_t)tid * 4u;
+  const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = 128u * PL * 4u;
+  const uint32_t wave_id = __builtin_amdgcn_readfirstlane((uint32_t)wave);
+  {
+    register uint32_t r120 asm("v120") = a_off;
+    register uint32_t r121 asm("v121") = b_off;
+    register uint32_t r122 asm("v122") = src_lo;
+    register uint32_t r123 asm("v123") = src_hi;
+    register uint32_t r124 asm("v124") = wb;
+    asm volatile(
+#include "k2_loop_p12.inc"
+        :
+        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_id), "v"(r120), "v"(r121), "v"(r122), "v"(r123), "v"(r124)
+        : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "v125",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+          "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99",
+          "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+          "v117", "v118", "v119");
+  }
+#ifdef DA_K2_DEBUG
+  if (g_k2_debug && tl.ti == 0 && tl.tj == 1) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(lds_ab);
+    for (int i = tid; i < 3 * STAGE_UNITS * 4; i += K2_THREADS) g_k2_debug[i] = w[i];
+  }
+#endif
+  // the lane's 32 packed mismatch counters (columns 2j, 2j+1 per register) come back through LDS
+  const uint32_t *wbp = reinterpret_cast<const uint32_t *>(lds_ab) + tid;
+  uint32_t mis[8][4];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mis[r][c] = wbp[(4 * r + c) * K2_THREADS];
+  const uint32_t nn = (uint32_t)n_hash * 0x10001u;             // two match counts per register (no borrow: each <= n_hash)
+  if (F64) {
+    double *ratio = reinterpret_cast<double *>(lds_ab);
+    __syncthreads();                                           // everyone has its counters: the area becomes the table
+    for (int c = tid; c <= n_hash; c += K2_THREADS) ratio[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
+    __syncthreads();
+    const char *tb = reinterpret_cast<const char *>(ratio);
+    double *out = reinterpret_cast<double *>(out_v);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                              // two of the lane's rows at a time keeps the epilogue in 128 VGPRs
+      double v0[8], v1[8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t m0 = nn - mis[2 * g][c], m1 = nn - mis[2 * g + 1][c];
+        v0[2 * c] = *reinterpret_cast<const double *>(tb + ((m0 << 3) & 0x7fff8u));
+        v0[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m0 >> 13) & 0x7fff8u));
+        v1[2 * c] = *reinterpret_cast<const double *>(tb + ((m1 << 3) & 0x7fff8u));
+        v1[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m1 >> 13) & 0x7fff8u));
+      }
+      double *orow = out + (I0 + 32 * g + 2 * ty) * ld + (J0 + 2 * tx);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        nt_store2(orow + 32 * q, v0[2 * q], v0[2 * q + 1]);
+        nt_store2(orow + ld + 32 * q, v1[2 * q], v1[2 * q + 1]);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)                              // mirrored store (src/minHash.cpp:176)
+        nt_store2(out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 32 * g + 2 * ty), v0[c], v1[c]);
+    }
+  } else {
+    uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint16_t *orow = out + (I0 + 32 * (r >> 1) + 2 * ty + (r & 1)) * ld + (J0 + 2 * tx);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - mis[r][g];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      uint16_t *orow = out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 2 * ty);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t lo = mis[2 * g][c >> 1], hi = mis[2 * g + 1][c >> 1];
+        const uint32_t pk = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - pk;
+      }
+    }
+  }
+}
+
 // PL = bit planes per group of 32 hash functions: 32 (raw uint32 values) or 16 / 12 / 8 (dictionary
 // codes of dict_kernels.hip, as many planes as the largest column dictionary needs: same equalities
 // off the diagonal, a fraction of the planes; the diagonal is forced).
@@ -264,7 +392,7 @@ template <bool SYM, bool F64, int PL>
 __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const uint32_t *__restrict__ planes, int64_t n, int n_hash, int64_t row_begin,
     int64_t row_end, int tile_stride, int upper_only, int TR, void *__restrict__ out_v, int64_t ld,
-    int64_t ntiles, int64_t per_xcd, int fold_q, int64_t fold_w, int band) {
+    int64_t ntiles, int64_t per_xcd, int fold_q, int64_t fold_w, int band, int only_edge) {
   // Row-block geometry: local tile row q covers global rows row_begin + q*tile_stride*128 + [0,128)
   // (tile_stride = 1: a contiguous block; = world: the cyclic shard of one rank) and is stored at
   // local rows q*128 + [0,128) of `out`.  upper_only skips tiles left of the diagonal.
@@ -316,6 +444,8 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   }
   if (I0 >= row_end || I0 >= n) return;
   if (!SYM && upper_only && J0 + K2_TILE <= I0) return;                     // tile entirely left of the diagonal
+  // the interior tiles were taken by k_mh_compare_a12 (hand-scheduled 12-plane loop): only border / diagonal tiles here
+  if (SYM && only_edge && a12_takes(tid2.ti, tid2.tj, n, ld, out_v, F64)) return;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -677,6 +807,12 @@ extern "C" int da_debug_set_k2_timing(unsigned long long *d_buf) {
 }
 #endif
 
+#ifdef DA_K2_DEBUG
+extern "C" int da_debug_set_k2_dump(uint32_t *d_buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k2_debug), &d_buf, sizeof(d_buf));
+}
+#endif
+
 int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_t n, int k,
                               int n_hash, const uint32_t *d_seeds, uint32_t *d_sig,
                               int64_t ld_sig, hipStream_t stream) {
@@ -711,9 +847,18 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   const int64_t nblocks = symmetric ? per_xcd * 8 : 8 * ceil_div(ceil_div(TR, band), 8) * (int64_t)band * T;
   if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
+  // symmetric 12-plane compares: interior tiles by the hand-scheduled kernel, the rest by the general one
+  const bool a12 = symmetric && plane_bits == 12 && !getenv("DYNAALIGN_K2_NO_ASM");
+  if (a12) {
+    if (kind == DA_OUT_F64)
+      hipLaunchKernelGGL(k_mh_compare_a12<true>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
+    else
+      hipLaunchKernelGGL(k_mh_compare_a12<false>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
+  }
+  const int only_edge = a12 ? 1 : 0;
 #define DA_K2(SYM, F64, PL)                                                                              \
   hipLaunchKernelGGL((k_mh_compare<SYM, F64, PL>), grid, block, 0, stream, d_planes, n, n_hash, \
-                     row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w, band)
+                     row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w, band, only_edge)
 #define DA_K2_PL(PL)                                                                     \
   do {                                                                                   \
     if (symmetric) { if (kind == DA_OUT_F64) DA_K2(true, true, PL); else DA_K2(true, false, PL); } \
