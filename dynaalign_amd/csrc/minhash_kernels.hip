@@ -311,8 +311,8 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
     register uint32_t r124 asm("v124") = wb;
     asm volatile(
 #include "k2_loop_p12.inc"
-        :
-        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_id), "v"(r120), "v"(r121), "v"(r122), "v"(r123), "v"(r124)
+        : "+v"(r122), "+v"(r123)                                 // the block reuses them as an operand buffer
+        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_id), "v"(r120), "v"(r121), "v"(r124)
         : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "v125",
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",

@@ -36,24 +36,24 @@ def mis(r, c2): return "v%d" % (64 + 4 * r + c2)
 def a(r): return "v[%d:%d]" % (96 + 2 * r, 97 + 2 * r)
 def ax(r): return "v%d" % (96 + 2 * r)
 def ay(r): return "v%d" % (97 + 2 * r)
-B = [("v[112:113]", "v112", "v113"), ("v[114:115]", "v114", "v115")]
+B = [("v[112:113]", "v112", "v113"), ("v[114:115]", "v114", "v115"), ("v[122:123]", "v122", "v123")]   # v122:123 is free once the DMA source has been copied
 
 # scalar registers are operands: %[lb] %[ns] %[st]; we need a few scratch SGPRs -> use s-clobbers s40..s47
 S_STAGE, S_SLOT, S_ISSUE_SLOT, S_TMP, S_M0, S_LEFT = "s40", "s41", "s42", "s43", "s44", "s45"
 
 def issue(stage_reg_expr_comment):
-    """DMA of one stage: 3 wave instructions of 1 KiB; source = v[122:123] + stage*ST (kept running in v[118:119]) + q*1024
-    (formed in v[116:117], which are dead here: the instruction's immediate offset would also move the LDS address);
-    LDS destination base in m0 = ring + slot*STAGE_BYTES + wave*3*1024 + q*1024 (S_M0 holds slot base + wave part)"""
+    """DMA of one stage: 3 wave instructions of 1 KiB each.  v[118:119] holds the source of instruction 0 on entry
+    and is advanced by 1 KiB in place for instructions 1 and 2 (the instruction's immediate offset is not used: it
+    may move the LDS address as well), i.e. it is left 2 KiB past the stage's first byte.
+    LDS destination in m0 = ring + slot*STAGE_BYTES + wave*3*1024 + q*1024 (S_M0 holds slot base + wave part)"""
     for q in range(3):
         e("s_add_u32 m0, %s, %d" % (S_M0, q * 1024))
         if q == 0:
             e("s_nop 0")
-            e("global_load_lds_dwordx4 v[118:119], off")
         else:
-            e("v_add_co_u32 v116, vcc, %d, v118" % (q * 1024))
-            e("v_addc_co_u32 v117, vcc, 0, v119, vcc")
-            e("global_load_lds_dwordx4 v[116:117], off")
+            e("v_add_co_u32 v118, vcc, 1024, v118")
+            e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
+        e("global_load_lds_dwordx4 v[118:119], off")
 
 def count_group():
     for r in range(8):
@@ -62,23 +62,27 @@ def count_group():
             e("v_bcnt_u32_b32 v125, %s, 0" % d(r, 2 * c2 + 1))
             e("v_lshl_add_u32 %s, v125, 16, %s" % (mis(r, c2), mis(r, c2)))
 
-def step(k, first, last):
-    """one 2-plane step: a[0..7] and b(col 0, buffer 0) are already in flight / loaded.
-    LDS reads return in order; outstanding before the step: [a0..a7 (if just issued), b0]"""
-    cur = 0
+def b_read(buf, k, c):
+    e("ds_read_b64 %s, v117 offset:%d" % (B[buf][0], c * ROW + k * 8))
+
+def step(k, first, last, cur):
+    """one 2-plane step.  On entry b(column 0) is in buffer `cur` and b(column 1) in the next buffer, both in flight
+    or landed, and so are a[0..7]; column operands are fetched TWO columns ahead (three buffers), row operands of the
+    next step right after their last use.  LDS reads return in order.  Returns the buffer holding the next step's b(0)."""
     for c in range(8):
-        # prefetch next column operand (or next step's column 0)
-        nxt = 1 - cur
-        if c + 1 < 8:
-            e("ds_read_b64 %s, v117 offset:%d" % (B[nxt][0], (c + 1) * ROW + k * 8))
-            pending_after = 1
+        # keep two column operands in flight: fetch column c+2 (or the next step's column c+2-8) into the third buffer
+        nxt2 = (cur + 2) % 3
+        if c + 2 < 8:
+            b_read(nxt2, k, c + 2); issued = True
         elif not last:
-            e("ds_read_b64 %s, v117 offset:%d" % (B[nxt][0], (k + 1) * 8))
-            pending_after = 1
+            b_read(nxt2, k + 1, c + 2 - 8); issued = True
         else:
-            pending_after = 0
-        # wait until b(cur) (and, for c == 0, all a) have landed: only the prefetch just issued may be outstanding
-        e("s_waitcnt lgkmcnt(%d)" % pending_after)
+            issued = False
+        # b(cur) must have landed: the reads issued after it are b(c+1) [if any] and the one just issued
+        younger = (1 if (c + 1 < 8 or not last) else 0) + (1 if issued else 0)
+        if c == 0:
+            younger = 1   # order so far: b(0), b(1), a[0..7], b(2): the row operands must have landed too
+        e("s_waitcnt lgkmcnt(%d)" % younger)
         for r in range(8):
             if first:
                 e("v_xor_b32 %s, %s, %s" % (d(r, c), ax(r), B[cur][2]))
@@ -87,12 +91,13 @@ def step(k, first, last):
             e("v_bitop3_b32 %s, %s, %s, %s bitop3:0xf6" % (d(r, c), d(r, c), ay(r), B[cur][1]))
             if c == 7 and not last:
                 e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW + (k + 1) * 8))
-        cur = nxt
+        cur = (cur + 1) % 3
     return cur
 
 e("// generated by tools/gen_k2_asm.py -- do not edit")
 # ---- setup
 e("s_mov_b32 %s, 0" % S_STAGE)                       # stage being computed
+e("s_sub_u32 %s, %%[st], 2048" % S_LEFT)               # the running DMA source sits 2 KiB into the stage it last issued
 e("v_mov_b32 v118, v122")
 e("v_mov_b32 v119, v123")
 for r in range(8):
@@ -106,7 +111,7 @@ e("s_mov_b32 %s, s46" % S_M0)
 issue("0")
 e("s_cmp_lt_u32 1, %[ns]")
 e("s_cbranch_scc0 1f")
-e("v_add_co_u32 v118, vcc, %[st], v118")
+e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
 e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
 e("s_add_u32 %s, s46, %d" % (S_M0, STAGE_BYTES))
 issue("1")
@@ -124,31 +129,34 @@ e("3:")
 e("s_waitcnt vmcnt(0)")
 e("4:")
 e("s_barrier")
-# issue stage + 2
+# LDS read bases of this stage
+e("v_add_u32 v116, %s, v120" % S_SLOT)
+e("v_add_u32 v117, %s, v121" % S_SLOT)
+# preload step 0 operands: b(col 0), b(col 1), then the 8 row operands (the order step() counts on)
+b_read(0, 0, 0)
+b_read(1, 0, 1)
+for r in range(8):
+    e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
+# issue stage + 2 while those reads fly (v125 / v124-free temps: the DMA address of q > 0 is formed in v[118:119] copies)
 e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
 e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
 e("s_cbranch_scc0 5f")
-e("v_add_co_u32 v118, vcc, %[st], v118")
+e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
 e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
 e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
 issue("st+2")
 e("5:")
-# LDS read bases of this stage
-e("v_add_u32 v116, %s, v120" % S_SLOT)
-e("v_add_u32 v117, %s, v121" % S_SLOT)
-# preload step 0 operands: b(col 0) first, then the 8 row operands
-e("ds_read_b64 %s, v117 offset:0" % B[0][0])
-for r in range(8):
-    e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
 # popcounts of the previous group (skipped for stage 0) while the reads fly
 e("s_cmp_eq_u32 %s, 0" % S_STAGE)
 e("s_cbranch_scc1 6f")
 count_group()
 e("6:")
 # the 6 steps.  NOTE: every step starts with b in buffer 0: 8 columns -> the buffer index is back at 0 after a step
+cur = 0
 for k in range(STEPS):
-    cur = step(k, first=(k == 0), last=(k == STEPS - 1))
-    assert cur == 0
+    cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)
+# 6 steps x 8 columns = 48 buffer advances = 0 mod 3: the next stage starts with buffer 0 again
+assert cur == 0
 # advance
 e("s_add_u32 %s, %s, %d" % (S_SLOT, S_SLOT, STAGE_BYTES))
 e("s_cmp_lt_u32 %s, %d" % (S_SLOT, 3 * STAGE_BYTES))
