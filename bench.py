@@ -242,8 +242,10 @@ def main():
         tiles = sum(T - t for t in range(rank, T, world))
         bytes_k2 = n * planes_row_bytes + tiles * 128 * 128 * 2   # this rank's uint16 tiles
     lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
-    traffic = pmc_traffic("k_mh_compare<true, true, %d>" % plane_bits) if world == 1 else None
-    roof = {"kernel": "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
+    # 12 code planes, symmetric mode: the hand-scheduled kernel does all but the diagonal / border tiles
+    k2_name = "k_mh_compare_a12<true>" if (world == 1 and plane_bits == 12) else "k_mh_compare<true, true, %d>" % plane_bits
+    traffic = pmc_traffic(k2_name) if world == 1 else None
+    roof = {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic["bytes"] if traffic and traffic.get("n") == n else None,
             "traffic_source": traffic["source"] if traffic and traffic.get("n") == n else None,

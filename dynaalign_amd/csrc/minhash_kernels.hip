@@ -415,7 +415,12 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
   const int64_t bid = blockIdx.x;
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
   TileId tid2;
-  if (SYM) {
+  if (SYM && only_edge) {
+    // the tiles k_mh_compare_a12 leaves: the T diagonal tiles, then the last tile column (when n is not a multiple of 128)
+    tid2.valid = bid < 2 * (int64_t)T - 1;
+    tid2.ti = bid < T ? (int)bid : (int)(bid - T);
+    tid2.tj = bid < T ? (int)bid : T - 1;
+  } else if (SYM) {
     const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
     if (L >= ntiles) return;
     tid2 = decode_tile(L, TR, T, true);
@@ -848,7 +853,8 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
   // symmetric 12-plane compares: interior tiles by the hand-scheduled kernel, the rest by the general one
-  const bool a12 = symmetric && plane_bits == 12 && !getenv("DYNAALIGN_K2_NO_ASM");
+  const bool a12 = symmetric && plane_bits == 12 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;   // = a12_takes' alignment test
   if (a12) {
     if (kind == DA_OUT_F64)
       hipLaunchKernelGGL(k_mh_compare_a12<true>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
@@ -856,6 +862,8 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
       hipLaunchKernelGGL(k_mh_compare_a12<false>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
   }
   const int only_edge = a12 ? 1 : 0;
+  // what is left for the general kernel then: the diagonal tiles + the last tile column, enumerated directly
+  if (a12) grid = dim3((unsigned)(2 * (int64_t)T - 1));
 #define DA_K2(SYM, F64, PL)                                                                              \
   hipLaunchKernelGGL((k_mh_compare<SYM, F64, PL>), grid, block, 0, stream, d_planes, n, n_hash, \
                      row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w, band, only_edge)

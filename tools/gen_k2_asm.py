@@ -16,6 +16,7 @@ import os
 import sys
 
 DUMP = int(os.environ.get("K2ASM_DUMP", "0"))   # debugging: leave the LDS ring as the loop left it (no counter write-back)
+SPREAD = int(os.environ.get("K2ASM_SPREAD", "0"))   # experiment: one DMA instruction before steps 0, 2 and 4 instead of three in a row
 SAFE = int(os.environ.get("K2ASM_SAFE", "0"))   # debugging: 1 = drain after every LDS read and DMA wait
 
 SEGS, STEPS = 3, 6           # 12 planes: 3 segments of 16 bytes = 6 steps of 8 bytes
@@ -54,6 +55,23 @@ def issue(stage_reg_expr_comment):
             e("v_add_co_u32 v118, vcc, 1024, v118")
             e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
         e("global_load_lds_dwordx4 v[118:119], off")
+
+def issue_piece(q):
+    """instruction q of the DMA of stage st+2, guarded by the stage test (uniform branch)"""
+    e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
+    e("s_cbranch_scc0 7f")
+    if q == 0:
+        e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
+        e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
+        e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
+    else:
+        e("v_add_co_u32 v118, vcc, 1024, v118")
+        e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
+    e("s_add_u32 m0, %s, %d" % (S_M0, q * 1024))
+    e("s_nop 0")
+    e("global_load_lds_dwordx4 v[118:119], off")
+    e("7:")
 
 def count_group():
     for r in range(8):
@@ -137,15 +155,18 @@ b_read(0, 0, 0)
 b_read(1, 0, 1)
 for r in range(8):
     e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
-# issue stage + 2 while those reads fly (v125 / v124-free temps: the DMA address of q > 0 is formed in v[118:119] copies)
-e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
-e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
-e("s_cbranch_scc0 5f")
-e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
-e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
-e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
-issue("st+2")
-e("5:")
+# issue stage + 2 while those reads fly
+if SPREAD:
+    issue_piece(0)
+else:
+    e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
+    e("s_cbranch_scc0 5f")
+    e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
+    e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
+    issue("st+2")
+    e("5:")
 # popcounts of the previous group (skipped for stage 0) while the reads fly
 e("s_cmp_eq_u32 %s, 0" % S_STAGE)
 e("s_cbranch_scc1 6f")
@@ -154,6 +175,8 @@ e("6:")
 # the 6 steps.  NOTE: every step starts with b in buffer 0: 8 columns -> the buffer index is back at 0 after a step
 cur = 0
 for k in range(STEPS):
+    if SPREAD and k in (2, 4):
+        issue_piece(k // 2)
     cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)
 # 6 steps x 8 columns = 48 buffer advances = 0 mod 3: the next stage starts with buffer 0 again
 assert cur == 0
