@@ -1,0 +1,26 @@
+"""The generated asm of k_mh_compare_a12 (csrc/k2_loop_p12.inc) against a CPU model of its instruction stream:
+register map, LDS addressing, ring bookkeeping, popcount packing, write-back order (tools/sim_k2_asm.py).
+Also: the committed include is what tools/gen_k2_asm.py generates."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.parametrize("tx,ty,seed", [(0, 0, 1), (5, 11, 2), (15, 15, 3), (7, 8, 4)])
+def test_generated_loop_counts_what_the_definition_says(tx, ty, seed):
+    import sim_k2_asm
+    issued, bad = sim_k2_asm.run(tx, ty, seed)
+    assert issued == 16 and bad == 0
+
+
+def test_committed_include_is_the_generators_output(tmp_path):
+    out = tmp_path / "k2.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("K2ASM_")}
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
+                          stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p12.inc")).read()

@@ -16,6 +16,8 @@ import os
 import sys
 
 DUMP = int(os.environ.get("K2ASM_DUMP", "0"))   # debugging: leave the LDS ring as the loop left it (no counter write-back)
+PRIO = int(os.environ.get("K2ASM_PRIO", "2"))       # wave priority inside the stage loop (0 = leave it alone): waves in their
+# plane loop issue ahead of waves that are decoding a tile or storing one -- 26.6 -> 25.6 ms on the same box
 SPREAD = int(os.environ.get("K2ASM_SPREAD", "0"))   # experiment: one DMA instruction before steps 0, 2 and 4 instead of three in a row
 SAFE = int(os.environ.get("K2ASM_SAFE", "0"))   # debugging: 1 = drain after every LDS read and DMA wait
 
@@ -113,6 +115,8 @@ def step(k, first, last, cur):
     return cur
 
 e("// generated by tools/gen_k2_asm.py -- do not edit")
+if PRIO:
+    e("s_setprio %d" % PRIO)
 # ---- setup
 e("s_mov_b32 %s, 0" % S_STAGE)                       # stage being computed
 e("s_sub_u32 %s, %%[st], 2048" % S_LEFT)               # the running DMA source sits 2 KiB into the stage it last issued
@@ -192,6 +196,8 @@ e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
 e("s_cbranch_scc1 2b")
 count_group()
 # ---- counters -> LDS (plane k of the write-back area = 1 KiB of lane-consecutive dwords), after everyone left the ring
+if PRIO:
+    e("s_setprio 0")
 e("s_barrier")
 if not DUMP:
     e("v_add_u32 v125, %[lb], v124")

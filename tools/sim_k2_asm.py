@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""CPU model of csrc/k2_loop_p12.inc (the hand-scheduled 12-plane stage loop of k_mh_compare_a12).
+
+Interprets the generated instruction stream for ONE lane (scalar control flow, LDS reads, v_xor / v_bitop3 /
+v_bcnt / v_lshl_add, the counter write-back); the DMA is modelled as "the stage's 12 KiB image appears in the ring
+slot when its first piece is issued", waits and barriers are ignored.  It checks what a timing-free model can check:
+the register map, the LDS addressing of both operands, the ring-slot bookkeeping over 16 stages, the popcount
+packing and the write-back order -- against a direct evaluation of  sum_g popcount(OR_p (a_p xor b_p)).
+Used by tests/test_k2_asm_model.py (no GPU needed)."""
+import os
+import random
+import re
+import sys
+
+INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynaalign_amd", "csrc", "k2_loop_p12.inc")
+
+
+def run(tx=5, ty=11, seed=1, inc=INC):
+    lines=[l.strip()[1:].split('\\n')[0] for l in open(inc) if l.startswith('"')]
+    NS=16; STAGE=12288; LB=0; ST=6144
+    random.seed(seed)
+    # stage data: for each stage s: 256 slots x 48 bytes. a slots 0..127, b slots 128..255
+    stages=[bytes(random.getrandbits(8) for _ in range(STAGE)) for s in range(NS)]
+    lds=bytearray(3*STAGE+4096)
+    V=[0]*256; S={}
+    S['lb']=LB; S['ns']=NS; S['st']=ST; S['wv']=0
+    V[120]=LB+ty*48; V[121]=LB+(128*3+tx*3)*16; V[122]=0; V[123]=0; V[124]=0  # tid 0 -> wave 0 (only data path matters)
+    labels={}
+    for i,l in enumerate(lines):
+        m=re.match(r'^(\d+):$',l)
+        if m: labels.setdefault(m.group(1),[]).append(i)
+    def sval(x):
+        x=x.strip()
+        if x.startswith('%['): return S[x[2:-1]]
+        if x.startswith('s'): return S.get(x,0)
+        if x=='m0': return S.get('m0',0)
+        return int(x,0)
+    def vreg(x): return int(x.strip()[1:])
+    def vpair(x):
+        m=re.match(r'v\[(\d+):(\d+)\]',x.strip()); return int(m.group(1))
+    pc=0; scc=0; issued=0; dma_q=0; wb={}
+    steps=0
+    while pc<len(lines):
+        l=lines[pc]; pc+=1
+        if re.match(r'^\d+:$',l) or l.startswith('//') or not l: continue
+        op,_,rest=l.partition(' ')
+        a=[x.strip() for x in rest.split(',')] if rest else []
+        if op=='s_mov_b32': S[a[0]]=sval(a[1])
+        elif op=='s_add_u32': S[a[0]]=(sval(a[1])+sval(a[2]))&0xffffffff
+        elif op=='s_sub_u32': S[a[0]]=(sval(a[1])-sval(a[2]))&0xffffffff
+        elif op=='s_mul_i32': S[a[0]]=(sval(a[1])*sval(a[2]))&0xffffffff
+        elif op=='s_cmp_lt_u32': scc=int(sval(a[0])<sval(a[1]))
+        elif op=='s_cmp_eq_u32': scc=int(sval(a[0])==sval(a[1]))
+        elif op=='s_cselect_b32': S[a[0]]=sval(a[1]) if scc else sval(a[2])
+        elif op in('s_cbranch_scc0','s_cbranch_scc1','s_branch'):
+            take = (op=='s_branch') or (op=='s_cbranch_scc0' and not scc) or (op=='s_cbranch_scc1' and scc)
+            if take:
+                t=a[0]; num=t[:-1]; d=t[-1]
+                cands=labels[num]
+                if d=='f': pc=min(c for c in cands if c>=pc)
+                else: pc=max(c for c in cands if c<pc)
+        elif op in('s_nop','s_waitcnt','s_barrier','s_setprio'): pass
+        elif op=='v_mov_b32': V[vreg(a[0])]= V[vreg(a[1])] if a[1].startswith('v') else int(a[1],0)
+        elif op=='v_lshrrev_b32': V[vreg(a[0])]=V[vreg(a[2])]>>int(a[1])
+        elif op=='v_readfirstlane_b32': S[a[0]]=V[vreg(a[1])]
+        elif op in('v_add_co_u32','v_addc_co_u32'): pass
+        elif op=='global_load_lds_dwordx4':
+            # emulate: whole stage copied when its first piece is issued (single-lane data-path model)
+            if dma_q==0:
+                s=issued; slot=(S['m0']-S['lb'])//STAGE   # wave 0: m0 = lb + slot*STAGE (+0)
+                lds[slot*STAGE:(slot+1)*STAGE]=stages[s]
+                issued+=1
+            dma_q=(dma_q+1)%3
+        elif op=='v_add_u32':
+            x=sval(a[1]) if not a[1].startswith('v') else V[vreg(a[1])]
+            V[vreg(a[0])]=(x+V[vreg(a[2])])&0xffffffff
+        elif op=='ds_read_b64':
+            base=vpair(a[0]); addr=V[vreg(a[1].split()[0])]; off=int(re.search(r'offset:(\d+)',l).group(1))
+            ad=addr+off-LB
+            V[base]=int.from_bytes(lds[ad:ad+4],'little'); V[base+1]=int.from_bytes(lds[ad+4:ad+8],'little')
+        elif op=='v_xor_b32': V[vreg(a[0])]=V[vreg(a[1])]^V[vreg(a[2])]
+        elif op=='v_bitop3_b32':
+            d_,s0,s1,s2=vreg(a[0]),vreg(a[1]),vreg(a[2]),vreg(a[3].split()[0])
+            V[d_]=V[s0]|(V[s1]^V[s2])
+        elif op=='v_bcnt_u32_b32':
+            x=V[vreg(a[2])] if a[2].startswith('v') else int(a[2],0)
+            V[vreg(a[0])]=bin(V[vreg(a[1])]).count('1')+x
+        elif op=='v_lshl_add_u32': V[vreg(a[0])]=((V[vreg(a[1])]<<int(a[2]))+V[vreg(a[3])])&0xffffffff
+        elif op=='ds_write_b32':
+            off=int(re.search(r'offset:(\d+)',l).group(1)); wb[off//1024]=V[vreg(a[1].split()[0])]
+        else:
+            raise RuntimeError("unhandled instruction: " + l)
+    # reference
+    def word(stage,slot,w): 
+        o=slot*48+w*4; return int.from_bytes(stages[stage][o:o+4],'little')
+    bad=0
+    for r in range(8):
+        for c in range(8):
+            arow=r*16+ty; bcol=128+c*16+tx
+            mism=0
+            for s in range(NS):
+                dd=0
+                for p in range(12):
+                    aw=word(s,arow,p); bw=word(s,bcol,p^1)
+                    dd|=aw^bw
+                mism+=bin(dd).count('1')
+            got=(wb[4*r+c//2]>>(16*(c&1)))&0xffff
+            if got!=mism: bad+=1
+    return issued, bad
+
+
+
+if __name__ == "__main__":
+    issued, bad = run()
+    print("stages issued", issued, "wrong counters", bad)
+    sys.exit(1 if bad or issued != 16 else 0)
