@@ -303,6 +303,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   const uint32_t wb = (uint32_t)tid * 4u;
   const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = 128u * PL * 4u;
   const uint32_t wave_id = __builtin_amdgcn_readfirstlane((uint32_t)wave);
+  const uint32_t src_lo_u = __builtin_amdgcn_readfirstlane(src_lo), src_hi_u = __builtin_amdgcn_readfirstlane(src_hi);   // lane 0's source
   {
     register uint32_t r120 asm("v120") = a_off;
     register uint32_t r121 asm("v121") = b_off;
@@ -312,8 +313,9 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
     asm volatile(
 #include "k2_loop_p12.inc"
         : "+v"(r122), "+v"(r123)                                 // the block reuses them as an operand buffer
-        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_id), "v"(r120), "v"(r121), "v"(r124)
-        : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "v125",
+        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_id), [sl] "s"(src_lo_u), [sh] "s"(src_hi_u),
+          "v"(r120), "v"(r121), "v"(r124)
+        : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s48", "s49", "s50", "s51", "v125",
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
           "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",

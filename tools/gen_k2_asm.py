@@ -18,6 +18,7 @@ import sys
 DUMP = int(os.environ.get("K2ASM_DUMP", "0"))   # debugging: leave the LDS ring as the loop left it (no counter write-back)
 PRIO = int(os.environ.get("K2ASM_PRIO", "2"))       # wave priority inside the stage loop (0 = leave it alone): waves in their
 # plane loop issue ahead of waves that are decoding a tile or storing one -- 26.6 -> 25.6 ms on the same box
+SADDR = int(os.environ.get("K2ASM_SADDR", "0"))     # experiment: DMA with an SGPR base + 32-bit lane offset (no VALU, half the address registers)
 SPREAD = int(os.environ.get("K2ASM_SPREAD", "0"))   # experiment: one DMA instruction before steps 0, 2 and 4 instead of three in a row
 SAFE = int(os.environ.get("K2ASM_SAFE", "0"))   # debugging: 1 = drain after every LDS read and DMA wait
 
@@ -51,6 +52,11 @@ def issue(stage_reg_expr_comment):
     LDS destination in m0 = ring + slot*STAGE_BYTES + wave*3*1024 + q*1024 (S_M0 holds slot base + wave part)"""
     for q in range(3):
         e("s_add_u32 m0, %s, %d" % (S_M0, q * 1024))
+        if SADDR:
+            e("s_add_u32 s50, s48, %d" % (q * 1024))
+            e("s_addc_u32 s51, s49, 0")
+            e("global_load_lds_dwordx4 v118, s[50:51]")
+            continue
         if q == 0:
             e("s_nop 0")
         else:
@@ -120,8 +126,14 @@ if PRIO:
 # ---- setup
 e("s_mov_b32 %s, 0" % S_STAGE)                       # stage being computed
 e("s_sub_u32 %s, %%[st], 2048" % S_LEFT)               # the running DMA source sits 2 KiB into the stage it last issued
-e("v_mov_b32 v118, v122")
-e("v_mov_b32 v119, v123")
+if SADDR:
+    e("s_mov_b32 s48, %[sl]")               # the wave's first source address (lane 0) as the scalar base ...
+    e("s_mov_b32 s49, %[sh]")
+    e("v_and_b32 v118, 0xfc, v124")         # ... and 16 * lane as the per-lane offset
+    e("v_lshlrev_b32 v118, 2, v118")
+else:
+    e("v_mov_b32 v118, v122")
+    e("v_mov_b32 v119, v123")
 for r in range(8):
     for c2 in range(4):
         e("v_mov_b32 %s, 0" % mis(r, c2))
@@ -133,8 +145,12 @@ e("s_mov_b32 %s, s46" % S_M0)
 issue("0")
 e("s_cmp_lt_u32 1, %[ns]")
 e("s_cbranch_scc0 1f")
-e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
-e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
+if SADDR:
+    e("s_add_u32 s48, s48, %[st]")
+    e("s_addc_u32 s49, s49, 0")
+else:
+    e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
+    e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
 e("s_add_u32 %s, s46, %d" % (S_M0, STAGE_BYTES))
 issue("1")
 e("1:")
@@ -166,8 +182,12 @@ else:
     e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
     e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
     e("s_cbranch_scc0 5f")
-    e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
-    e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
+    if SADDR:
+        e("s_add_u32 s48, s48, %[st]")
+        e("s_addc_u32 s49, s49, 0")
+    else:
+        e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
+        e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
     e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
     issue("st+2")
     e("5:")
