@@ -298,11 +298,25 @@ def main():
     # shard compare -> histogram -> ONE all-reduce of n_hash+1 words -> exact type-7 quantile -> local edges.
     # No N x N exchange, so this is the variant of the path whose whole-job time scales with the rank count.
     if not a.no_edges:
-        eplan = sharding.Plan(n, rank, world, sharding.MH_TILE)
-        ework = sharding.Workspace(eplan, "cuda") if world == 1 else work
+        if world == 1:
+            # one GPU: nothing to shard -- symmetric uint16 compare, histogram of the upper triangle, exact quantile, edges
+            cnt16 = out.view(-1).view(torch.int16)[:n * n].view(n, n)          # the f64 result buffer is free here: reuse its first 20 GB
+            values = np.arange(n_hash + 1, dtype=np.float64) / n_hash
 
-        def run_edges():
-            return sharding.mh_edges_sharded(eplan, ework, signatures_and_planes(), n_hash, 0.8)
+            def run_edges():
+                pl = signatures_and_planes()
+                device.mh_compare(pl, n, n_hash, 0, n, True, _capi.DA_OUT_COMPACT, out=cnt16)
+                h = device.upper_histogram(cnt16, n, n_hash + 1).cpu().numpy().astype(np.uint64)
+                thr = da.quantile_type7(h, values, 0.8)
+                keep = (~(values < thr)) & (np.arange(n_hash + 1) != 0)
+                m = int(h[keep].sum()) + n
+                ei, ej, evv, c = device.extract_edges(cnt16, n, keep, m)
+                return thr, ei, ej, evv, c
+        else:
+            eplan = sharding.Plan(n, rank, world, sharding.MH_TILE)
+
+            def run_edges():
+                return sharding.mh_edges_sharded(eplan, work, signatures_and_planes(), n_hash, 0.8)
         run_edges()
         sync()
         t0 = time.perf_counter()
@@ -316,7 +330,8 @@ def main():
             t_e = float(t.item())
             dist.all_reduce(tot)
         line["edges"] = {"workload": "similarityMH k=4 n_hash=500 + quantile(S[upper.tri(S)], 0.8) threshold -> edge list "
-                                     "(R/clusterbreak.R:219-221), same %d peptides; edges stay distributed over the ranks" % n,
+                                     "(R/clusterbreak.R:219-221), same %d peptides; %s" % (n, "one GPU: symmetric uint16 compare -> histogram -> "
+                                     "quantile -> edges" if world == 1 else "edges stay distributed over the ranks"),
                          "value": pairs_mh / t_e, "unit": "pairs/s", "ms": t_e * 1e3, "threshold": thr,
                          "edges_total": int(tot.item()), "edge_list_bytes": int(tot.item()) * 10}
         del ei, ej, evv
