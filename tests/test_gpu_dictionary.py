@@ -222,3 +222,28 @@ def test_crafted_signature_columns(da, n):
         a = device.mh_compare(pc, n, n_hash, kind=_capi.DA_OUT_COMPACT)
         b = device.mh_compare(p32, n, n_hash, kind=_capi.DA_OUT_COMPACT)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,n_hash", [(1000, 500), (1153, 70), (2048, 33), (640, 31)])
+def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash):
+    """symmetric 12-plane compares run the hand-scheduled stage loop on interior tiles (k_mh_compare_a12) and the
+    compiled kernel on diagonal / border tiles; DYNAALIGN_K2_NO_ASM=1 runs the compiled kernel everywhere.  Both
+    outputs, both output kinds, 1 / 2 / 3 / 16 stages, n a multiple of 128 or not."""
+    import torch
+    from dynaalign_amd import device, synth, _capi
+    res, off = synth.h3n2_like(n, 20)
+    n, sig_h, p12, p32 = _planes_both(da, res, off, 4, n_hash, min_bits=12)
+    assert p12.bits == 12
+    want = _counts(sig_h)
+    got = {}
+    for tag in ("asm", "compiled"):
+        if tag == "compiled":
+            os.environ["DYNAALIGN_K2_NO_ASM"] = "1"
+        try:
+            got[tag] = (device.mh_compare(p12, n, n_hash, kind=_capi.DA_OUT_COMPACT).cpu().numpy().view(np.uint16),
+                        device.mh_compare(p12, n, n_hash).cpu().numpy())
+        finally:
+            os.environ.pop("DYNAALIGN_K2_NO_ASM", None)
+    assert np.array_equal(got["asm"][0], want) and np.array_equal(got["compiled"][0], want)
+    assert np.array_equal(got["asm"][1].view(np.uint64), got["compiled"][1].view(np.uint64))
+    assert np.array_equal(got["asm"][1], want.astype(np.float64) / n_hash)
