@@ -216,8 +216,9 @@ e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
 e("s_cbranch_scc1 2b")
 count_group()
 # ---- counters -> LDS (plane k of the write-back area = 1 KiB of lane-consecutive dwords), after everyone left the ring
-if PRIO:
-    e("s_setprio 0")
+EPRIO = int(os.environ.get("K2ASM_EPRIO", "0"))     # wave priority after the loop (tile epilogue)
+if PRIO or EPRIO:
+    e("s_setprio %d" % EPRIO)
 e("s_barrier")
 if not DUMP:
     e("v_add_u32 v125, %[lb], v124")
