@@ -20,6 +20,8 @@ PRIO = int(os.environ.get("K2ASM_PRIO", "2"))       # wave priority inside the s
 # plane loop issue ahead of waves that are decoding a tile or storing one -- 26.6 -> 25.6 ms on the same box
 SADDR = int(os.environ.get("K2ASM_SADDR", "0"))     # experiment: DMA with an SGPR base + 32-bit lane offset (no VALU, half the address registers)
 SPREAD = int(os.environ.get("K2ASM_SPREAD", "0"))   # experiment: one DMA instruction before steps 0, 2 and 4 instead of three in a row
+SDWA = int(os.environ.get("K2ASM_SDWA", "0"))       # experiment: add the odd column's popcount into the counter's high half with an SDWA add
+EPRIO = int(os.environ.get("K2ASM_EPRIO", "0"))     # wave priority after the loop (tile epilogue)
 SAFE = int(os.environ.get("K2ASM_SAFE", "0"))   # debugging: 1 = drain after every LDS read and DMA wait
 
 SEGS, STEPS = 3, 6           # 12 planes: 3 segments of 16 bytes = 6 steps of 8 bytes
@@ -86,7 +88,10 @@ def count_group():
         for c2 in range(4):
             e("v_bcnt_u32_b32 %s, %s, %s" % (mis(r, c2), d(r, 2 * c2), mis(r, c2)))
             e("v_bcnt_u32_b32 v125, %s, 0" % d(r, 2 * c2 + 1))
-            e("v_lshl_add_u32 %s, v125, 16, %s" % (mis(r, c2), mis(r, c2)))
+            if SDWA:
+                e("v_add_u32_sdwa %s, v125, %s dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1" % (mis(r, c2), mis(r, c2)))
+            else:
+                e("v_lshl_add_u32 %s, v125, 16, %s" % (mis(r, c2), mis(r, c2)))
 
 def b_read(buf, k, c):
     e("ds_read_b64 %s, v117 offset:%d" % (B[buf][0], c * ROW + k * 8))
@@ -216,7 +221,6 @@ e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
 e("s_cbranch_scc1 2b")
 count_group()
 # ---- counters -> LDS (plane k of the write-back area = 1 KiB of lane-consecutive dwords), after everyone left the ring
-EPRIO = int(os.environ.get("K2ASM_EPRIO", "0"))     # wave priority after the loop (tile epilogue)
 if PRIO or EPRIO:
     e("s_setprio %d" % EPRIO)
 e("s_barrier")
