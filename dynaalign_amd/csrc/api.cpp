@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -112,6 +113,54 @@ struct DeviceInput {
 // staged at ~17 GB/s (measured, profiles/r01_d_host_path.json); this ring of pinned staging buffers
 // keeps the DMA engine streaming while host threads copy finished chunks into the destination.
 // (hipHostRegister of the destination would pin up to 80 GB of R's heap -- not ours to pin.)
+// A few persistent host threads that copy pieces of a pinned chunk into the destination (the destination's
+// first-touch page faults are what they parallelise; one pool per call, not one thread per chunk).
+class CopyPool {
+ public:
+  explicit CopyPool(int workers) {
+    for (int w = 0; w < workers; ++w) th_.emplace_back([this, w]() { run(w); });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  // dst[0, len) <- src[0, len), split over the workers + the calling thread; returns when all parts are done
+  void copy(char *dst, const char *src, size_t len) {
+    const size_t parts = th_.size() + 1, part = (len + parts - 1) / parts;
+    { std::lock_guard<std::mutex> g(m_); dst_ = dst; src_ = src; len_ = len; part_ = part; pending_ = (int)th_.size(); ++gen_; }
+    cv_.notify_all();
+    memcpy(dst, src, std::min(part, len));
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this]() { return pending_ == 0; });
+  }
+
+ private:
+  void run(int w) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> g(m_);
+      cv_.wait(g, [&]() { return gen_ != seen; });
+      seen = gen_;
+      if (stop_) return;
+      char *d = dst_; const char *s = src_; const size_t len = len_, part = part_;
+      g.unlock();
+      const size_t b = (size_t)(w + 1) * part;
+      if (b < len) memcpy(d + b, s + b, std::min(part, len - b));
+      g.lock();
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+  char *dst_ = nullptr; const char *src_ = nullptr;
+  size_t len_ = 0, part_ = 0;
+  int pending_ = 0;
+};
+
 int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
   constexpr size_t CHUNK = (size_t)64 << 20;
   constexpr int RING = 4, MAX_WORKERS = 32;
@@ -125,7 +174,8 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
   Slot ring[RING];
   hipStream_t st = nullptr;
   int rc = DA_OK;
-  auto cleanup = [&]() {
+  auto cleanup = [&]() {                 // copies still in flight on `st` must not outlive the pinned slots they write
+    if (st) (void)hipStreamSynchronize(st);
     for (auto &s : ring) { if (s.pin) (void)hipHostFree(s.pin); if (s.ev) (void)hipEventDestroy(s.ev); }
     if (st) (void)hipStreamDestroy(st);
   };
@@ -137,28 +187,21 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
   for (auto &s : ring)
     if (!check(hipHostMalloc(&s.pin, CHUNK, hipHostMallocDefault), "hipHostMalloc") ||
         !check(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming), "hipEventCreate")) { cleanup(); return rc; }
-  DA_HIP_TRY(hipDeviceSynchronize());  // the producing kernels ran on the null stream
-  const size_t nchunk = (bytes + CHUNK - 1) / CHUNK;
-  auto host_copy = [&](size_t c) {     // pinned slot -> destination, split over a few threads
-    const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
-    const char *src = static_cast<const char *>(ring[c % RING].pin);
-    char *d = static_cast<char *>(dst) + off;
-    std::thread th[MAX_WORKERS];
-    const size_t part = (len + WORKERS - 1) / WORKERS;
-    for (int w = 1; w < WORKERS; ++w)
-      th[w - 1] = std::thread([=]() { const size_t b = w * part; if (b < len) memcpy(d + b, src + b, std::min(part, len - b)); });
-    memcpy(d, src, std::min(part, len));
-    for (int w = 1; w < WORKERS; ++w) th[w - 1].join();
-  };
-  for (size_t c = 0; c < nchunk + RING - 1 && rc == DA_OK; ++c) {
-    if (c < nchunk) {                  // slot c % RING was drained RING iterations ago
-      const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
-      check(hipMemcpyAsync(ring[c % RING].pin, static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
-      check(hipEventRecord(ring[c % RING].ev, st), "hipEventRecord");
-    }
-    if (c >= RING - 1) {
-      const size_t done = c - (RING - 1);
-      if (check(hipEventSynchronize(ring[done % RING].ev), "hipEventSynchronize")) host_copy(done);
+  if (!check(hipDeviceSynchronize(), "hipDeviceSynchronize")) { cleanup(); return rc; }   // the producing kernels ran on the null stream
+  {
+    CopyPool pool(WORKERS - 1);
+    const size_t nchunk = (bytes + CHUNK - 1) / CHUNK;
+    for (size_t c = 0; c < nchunk + RING - 1 && rc == DA_OK; ++c) {
+      if (c < nchunk) {                  // slot c % RING was drained RING iterations ago
+        const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
+        if (!check(hipMemcpyAsync(ring[c % RING].pin, static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") ||
+            !check(hipEventRecord(ring[c % RING].ev, st), "hipEventRecord")) break;
+      }
+      if (c >= RING - 1) {
+        const size_t done = c - (RING - 1), off = done * CHUNK, len = std::min(CHUNK, bytes - off);
+        if (!check(hipEventSynchronize(ring[done % RING].ev), "hipEventSynchronize")) break;
+        pool.copy(static_cast<char *>(dst) + off, static_cast<const char *>(ring[done % RING].pin), len);
+      }
     }
   }
   cleanup();

@@ -275,12 +275,14 @@ __device__ __forceinline__ bool a12_takes(int ti, int tj, int64_t n, int64_t ld,
 // 4 waves per SIMD.  The C++ around it decodes the tile, hands five per-lane values over in v120..v124, reads the
 // 32 packed mismatch counters back from LDS and stores the tile like k_mh_compare's straight-line epilogue.
 // Symmetric mode, interior off-diagonal tiles only (a12_takes).
+constexpr int K2_A12_TABLE_MAX = 3 * 2 * K2_TILE * 3 * 16 / 8;   // doubles that fit the 12-plane kernel's ring (3 stages x 256 rows x 48 B)
 template <bool F64>
 __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
                                                                   void *__restrict__ out_v, int64_t ld, int64_t ntiles,
                                                                   int64_t per_xcd) {
   constexpr int PL = 12, SEGS = 3, STAGE_UNITS = 2 * K2_TILE * SEGS;
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring; afterwards counters, then the ratio table
+  static_assert(sizeof(lds_ab) / (sizeof(double)) == K2_A12_TABLE_MAX, "launch_mh_compare's table guard must match the ring size");
   const int64_t bid = blockIdx.x;
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
   const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
         : "+v"(r122), "+v"(r123)                                 // the block reuses them as an operand buffer
         : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_id), [sl] "s"(src_lo_u), [sh] "s"(src_hi_u),
           "v"(r120), "v"(r121), "v"(r124)
-        : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s48", "s49", "s50", "s51", "v125",
+        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",   // m0 is saved in s47 and restored by the block
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
           "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
@@ -491,8 +493,10 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
 #pragma unroll
     for (int q = 0; q < SEGS; ++q) {
       const uint32_t *g = src[q] + stage * (128 * SP);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                   :: "v"(g), "s"(base + (uint32_t)(q * 64 * sizeof(uint4))) : "memory", "m0");
+      // m0 (the LDS-DMA destination) is compiler-reserved: saved and restored inside the statement instead of clobbered
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0) : "v"(g), "s"(base + (uint32_t)(q * 64 * sizeof(uint4))) : "memory");
     }
   };
   // before the barrier that opens stage s: its SEGS copies must have landed; those of the `younger`
@@ -859,7 +863,10 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   if (nblocks > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)nblocks), block(K2_THREADS);
   // symmetric 12-plane compares: interior tiles by the hand-scheduled kernel, the rest by the general one
+  // (float64 output: its count -> double table of n_hash + 1 entries lives in the kernel's 36 KiB ring, K2_A12_TABLE_MAX
+  // doubles; a larger n_hash stays with k_mh_compare, which divides directly when its table does not fit)
   const bool a12 = symmetric && plane_bits == 12 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+                   (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A12_TABLE_MAX) &&
                    (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;   // = a12_takes' alignment test
   if (a12) {
     if (kind == DA_OUT_F64)

@@ -13,6 +13,9 @@ row.  The compact payload (2 B/pair instead of 8) and the folded block layout (o
 upper triangle travels) are what make the gather affordable: at N = 100k, P = 8 each GPU
 receives 8.8 GB instead of 70 GB.
 
+Seeds: with no explicit seed the reference draws one from std::random_device per call; here rank 0 draws it
+and broadcasts it (`shared_seed`) -- ranks hashing with different families would assemble a meaningless matrix.
+
 The orchestration (`Plan`, `all_pairs_sharded`) is independent of where the blocks come from,
 so the world_size-2 gloo tests drive it on CPU with blocks produced by the test oracle; the
 product path (`mh_sharded_step`, `nw_sharded_step`) feeds it from the HIP kernels only.
@@ -76,6 +79,27 @@ class Plan:
                 rows = min((t + 1) * self.tile, self.n) - t * self.tile
                 tot += rows * (self.n - t * self.tile)
         return tot
+
+
+def shared_seed(seed=None, group=None):
+    """The hash seed every rank of the job must use.  All ranks rebuild all signatures themselves, so they have
+    to draw the SAME hash family: the reference's default -- no seed, std::random_device (src/minHash.cpp:73) --
+    resolved independently per process would gather blocks computed under different hash functions.  Rank 0
+    resolves the seed (argument > set_option("seed") > DYNAALIGN_SEED > random_device) and broadcasts it."""
+    from .similarity import _resolve_seed
+    s = _resolve_seed(seed)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([s], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        s = int(t.item())
+    return s & 0xFFFFFFFF
+
+
+def shared_hash_family(n_hash, seed=None, group=None):
+    """n_hash hash seeds (reference HashFamily, src/minHash.cpp:73-81), identical on every rank."""
+    from .similarity import hash_family_seeds
+    return hash_family_seeds(shared_seed(seed, group), n_hash)
 
 
 def all_pairs_sharded(plan, local_block, gathered, finalize, group=None):

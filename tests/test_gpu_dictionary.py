@@ -247,3 +247,25 @@ def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash):
     assert np.array_equal(got["asm"][0], want) and np.array_equal(got["compiled"][0], want)
     assert np.array_equal(got["asm"][1].view(np.uint64), got["compiled"][1].view(np.uint64))
     assert np.array_equal(got["asm"][1], want.astype(np.float64) / n_hash)
+
+
+@pytest.mark.parametrize("n_hash", [4607, 4608, 7000])
+def test_large_n_hash_with_interior_tiles(da, n_hash):
+    """The hand-scheduled 12-plane kernel keeps its count -> double table (n_hash + 1 entries) in its 36 KiB ring:
+    4608 doubles.  n_hash = 4607 is the last that fits; larger ones must take the general kernel (direct divide).
+    n = 400 gives interior off-diagonal tiles; duplicated sequences give match counts == n_hash off the diagonal,
+    i.e. reads at the very end of the table."""
+    from dynaalign_amd import device, synth, _capi
+    res, off = synth.h3n2_like(400, 20)
+    res = res.reshape(400, 20).copy()
+    res[300:400] = res[0:100]                                   # rows 300.. duplicate rows 0..: count == n_hash in tile (0, 2/3)
+    res = res.reshape(-1)
+    n, sig_h, p12, p32 = _planes_both(da, res, off, 4, n_hash, min_bits=12)
+    assert p12.bits == 12
+    want = _counts(sig_h)
+    assert want[0, 300] == n_hash
+    c12 = device.mh_compare(p12, n, n_hash, kind=_capi.DA_OUT_COMPACT).cpu().numpy().view(np.uint16)
+    assert np.array_equal(c12, want)
+    f12 = device.mh_compare(p12, n, n_hash).cpu().numpy()
+    want_f = want.astype(np.float64) / n_hash                  # src/minHash.cpp:174
+    assert np.array_equal(f12.view(np.uint64), want_f.view(np.uint64))

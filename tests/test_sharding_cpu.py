@@ -173,3 +173,38 @@ def test_sharded_edges_all_reduce_matches_dense_threshold(built):
     assert {thr for _, thr, _ in results} == {thr_w}
     assert [(a, b) for a, b, _ in got] == list(zip(iw.tolist(), jw.tolist()))
     assert [c / 64 for _, _, c in got] == ww.tolist()
+
+
+def _seed_rank_main(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.pop("DYNAALIGN_SEED", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dynaalign_amd  # noqa: F401
+        own = dynaalign_amd.similarity._resolve_seed(None)              # what each process would draw on its own
+        s = sharding.shared_seed(None)                                  # the reference's default: no seed given
+        fam = sharding.shared_hash_family(16, None)                     # a second draw: again one family for all ranks
+        explicit = sharding.shared_seed(1000 + rank)                    # explicit but inconsistent seeds: rank 0's wins
+        q.put((rank, own, s, fam.tolist(), explicit))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_default_seed_is_one_hash_family_for_all_ranks(built):
+    """seed=None (std::random_device, reference src/minHash.cpp:73) resolved per process would make the ranks hash
+    with different families; shared_seed broadcasts rank 0's draw."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seed_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, own0, s0, fam0, e0), (_, own1, s1, fam1, e1) = results
+    assert s0 == s1 and fam0 == fam1 and len(fam0) == 16
+    assert e0 == e1 == 1000
+    assert 0 <= s0 < 2 ** 32

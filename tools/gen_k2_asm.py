@@ -126,6 +126,7 @@ def step(k, first, last, cur):
     return cur
 
 e("// generated by tools/gen_k2_asm.py -- do not edit")
+e("s_mov_b32 s47, m0")                                # m0 is compiler-reserved: saved here, restored at the end of the block
 if PRIO:
     e("s_setprio %d" % PRIO)
 # ---- setup
@@ -230,6 +231,7 @@ if not DUMP:
         for c2 in range(4):
             e("ds_write_b32 v125, %s offset:%d" % (mis(r, c2), (4 * r + c2) * 1024))
     e("s_waitcnt lgkmcnt(0)")
+e("s_mov_b32 m0, s47")
 
 with open(sys.argv[1], "w") as f:
     for l in out:
