@@ -11,7 +11,7 @@ full set can stay in HBM and a recursion level only needs K1b (codes of the subs
 
 The only difference to calling the reference per level is the random stream (the reference draws fresh
 seeds per call, src/minHash.cpp:73,137); the contract -- MinHash estimates under one hash family -- holds.
-Louvain / the recursion itself stay with the caller (igraph in R).
+The recursion itself (and its Louvain step) is restated in dynaalign_amd/clusterbreak.py, which drives this session.
 """
 import numpy as np
 import torch
@@ -48,8 +48,9 @@ class MinHashSession:
         out = device.mh_compare(planes, m, self.n_hash)
         return SimilarityMatrix(out.cpu().numpy())
 
-    def edges(self, idx=None, thresh_p=0.8):
-        """(threshold, i, j, weight) of the subset after clusterbreak's quantile threshold, i <= j positions in idx"""
+    def edges(self, idx=None, thresh_p=0.8, sort=True):
+        """(threshold, i, j, weight) of the subset after clusterbreak's quantile threshold, i <= j positions in idx;
+        sort=False leaves the edges in the order the device appended them (da_louvain canonicalises anyway)"""
         planes, m = self.planes(idx)
         if m < 2:
             raise _capi.DynaAlignError(_capi.DA_ERR_BAD_ARG, "the threshold is a quantile of the strict upper triangle: need >= 2 sequences")
@@ -64,5 +65,7 @@ class MinHashSession:
         got = int(c.item())
         assert got == cap, (got, cap)
         ei, ej, ev = ei[:got].cpu().numpy(), ej[:got].cpu().numpy(), ev[:got].cpu().numpy().view(np.uint16)
+        if not sort:
+            return thr, ei, ej, values[ev]
         order = np.lexsort((ej, ei))
         return thr, ei[order], ej[order], values[ev[order]]

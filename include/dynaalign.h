@@ -265,6 +265,20 @@ int da_dev_shard_extract_edges(const uint16_t *d_local, int64_t ld, int64_t n, i
                                int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
                                uint64_t *d_count, void *stream);
 
+/* ---- the caller's clustering step (reference R/clusterbreak.R:112-136, netcluster) ------------
+ * igraph::cluster_louvain(graph_from_adjacency_matrix(S, mode = "upper", weighted = TRUE),
+ *                         weights = E(g)$weight, resolution = 1.05)$membership
+ * on an edge list (i, j, weight), 0-based, i == j = self-loop (the thresholded matrix keeps its 1.0
+ * diagonal, R/clusterbreak.R:221), (i, j) and (j, i) the same undirected edge.  HOST code, like igraph in
+ * the reference: multilevel modularity optimisation with igraph's conventions (loops count twice in a
+ * vertex's strength; the last level's membership, renumbered 1.. by first appearance).  Deterministic in
+ * (graph, seed) whatever the order of the edge arrays; igraph's own result depends on R's RNG stream and
+ * is not reproducible outside R.  membership_out: n_vertices ids starting at 1; modularity_out /
+ * levels_out may be NULL. */
+int da_louvain(int64_t n_vertices, int64_t n_edges, const int32_t *ei, const int32_t *ej, const double *ew,
+               double resolution, uint32_t seed, int32_t *membership_out, double *modularity_out,
+               int32_t *levels_out);
+
 /* name -> id for da_dev_nw; -1 + DA_ERR_BAD_MATRIX message when unknown. */
 int da_matrix_id(const char *matrix_name);
 
