@@ -30,6 +30,9 @@ SIGNATURES = {
     "da_hash_family_seeds": (_i32, [_u32, _i32, _vp]),
     "da_random_seed": (_u32, []),
     "da_similarity_mh": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "da_similarity_mh_opts": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "da_similarity_nw_opts": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _vp, _vp]),
+    "da_rccl_available": (_i32, []),
     "da_minhash_signatures": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "da_mh_counts": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _i64, _vp]),
     "da_similarity_nw": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, _vp]),
@@ -62,6 +65,28 @@ SIGNATURES = {
     "da_dev_symmetrize": (_i32, [_vp, _i64, _i64, _i32, _vp]),
     "da_dev_widen": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
+
+DA_EXCHANGE = {"rows": 0, "allgather": 1, "peercopy": 2}
+DA_PHASES = ("setup", "compute", "exchange", "finalize", "d2h", "total")
+
+
+class DaOpts(C.Structure):
+    """struct da_opts (include/dynaalign.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)),
+                ("exchange", C.c_int32), ("reserved", C.c_uint32), ("phase_ms", C.POINTER(C.c_double))]
+
+
+def make_opts(devices=None, exchange="rows"):
+    """-> (DaOpts, keepalive): the struct for da_similarity_*_opts; keepalive[1] receives the phase times (ms)"""
+    devs = [] if devices is None else [int(d) for d in devices]
+    if exchange not in DA_EXCHANGE:
+        raise ValueError("exchange must be one of %s" % sorted(DA_EXCHANGE))
+    dev_arr = (C.c_int32 * max(len(devs), 1))(*devs)
+    phases = (C.c_double * len(DA_PHASES))()
+    o = DaOpts(C.sizeof(DaOpts), len(devs), C.cast(dev_arr, C.POINTER(C.c_int32)), DA_EXCHANGE[exchange], 0,
+               C.cast(phases, C.POINTER(C.c_double)))
+    return o, (dev_arr, phases)
+
 
 _lib = None
 

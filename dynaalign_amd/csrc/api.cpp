@@ -7,6 +7,8 @@
 #include <climits>
 #include <cmath>
 #include <condition_variable>
+#include <cstddef>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -900,6 +902,381 @@ int da_nw_pairs(const uint8_t *residues, const int64_t *offsets, int64_t n, cons
                 int32_t *len_out, int32_t *score_out) {
   return nw_host_common(residues, offsets, n, matrix_name, gap_open, gap_ext, row_begin, row_end, nullptr,
                         matches_out, len_out, score_out);
+}
+
+
+// ------------------------------------------------- multi-device host entry points (SURVEY 8(b) da_opts, 8(e))
+// ONE process drives several GPUs: a host thread per device (hipSetDevice is per thread), every device holds all
+// sequences and rebuilds all signatures itself (2 MB in), the pair space is split, and every device copies ITS
+// rows of the result straight into the caller's matrix -- P PCIe links instead of one, which is where more GPUs help
+// the host-pointer boundary (the 80 GB result is PCIe-bound).  Exchange modes:
+//   DA_EXCHANGE_ROWS      no device-to-device traffic: device p computes the contiguous row block it will copy out
+//                         (full rows: twice the triangle's compare work, still far below the copy time);
+//   DA_EXCHANGE_ALLGATHER the north-star's shape: cyclic upper-triangle shards -> ONE ncclAllGather over xGMI (RCCL,
+//                         communicators from ncclCommInitAll) -> mirror + widen to the full matrix on every device;
+//   DA_EXCHANGE_PEERCOPY  the same shards exchanged by direct hipMemcpyPeerAsync reads of every peer's block: xGMI is
+//                         point-to-point, so P - 1 concurrent peer copies use all links at once where a ring is
+//                         per-link bound; needs no RCCL.
+// RCCL is bound at run time (dlopen of librccl.so.1): a process that already carries an RCCL (PyTorch's) keeps one copy.
+}  // extern "C"  (reopened below)
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <array>
+#include <chrono>
+
+namespace da {
+namespace {
+
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+  bool load() {
+    if (h) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+      why = dlerror();
+    }
+    if (!h) return false;
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(h, "ncclAllGather"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !AllGather || !GetErrorString) { why = "librccl lacks ncclCommInitAll / ncclAllGather"; h = nullptr; return false; }
+    return true;
+  }
+};
+Rccl &rccl() { static Rccl r; return r; }
+std::mutex &rccl_mutex() { static std::mutex m; return m; }
+
+// all ranks arrive with their status; everyone learns whether all were fine
+class StatusBarrier {
+ public:
+  explicit StatusBarrier(int n) : n_(n) {}
+  bool arrive(bool ok) {
+    std::unique_lock<std::mutex> g(m_);
+    if (!ok) all_ok_ = false;
+    const uint64_t gen = gen_;
+    if (++count_ == n_) { count_ = 0; result_ = all_ok_; ++gen_; cv_.notify_all(); return result_; }
+    cv_.wait(g, [&]() { return gen_ != gen; });
+    return result_;
+  }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int n_, count_ = 0;
+  uint64_t gen_ = 0;
+  bool all_ok_ = true, result_ = true;
+};
+
+enum { PH_SETUP = 0, PH_COMPUTE, PH_EXCHANGE, PH_FINALIZE, PH_D2H, PH_TOTAL, PH_COUNT };
+
+struct Multi {
+  int P = 1, exchange = DA_EXCHANGE_ROWS;
+  std::vector<int> devs;
+  std::vector<ncclComm_t> comms;
+  std::vector<const void *> block;                 // rank p's block to exchange (device pointer), PEERCOPY
+  std::vector<int> rc;
+  std::vector<std::string> msg;
+  std::vector<std::array<double, PH_COUNT>> ms;
+  std::unique_ptr<StatusBarrier> bar;
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// rows rank p copies to the host: contiguous, boundaries on 128-row tiles
+void row_split(int64_t n, int P, int p, int64_t *r0, int64_t *r1) {
+  const int64_t T = ceil_div(n, 128);
+  *r0 = std::min(n, ceil_div(T * p, P) * 128);
+  *r1 = std::min(n, ceil_div(T * (p + 1), P) * 128);
+}
+
+int parse_opts(const da_opts *o, Multi &m) {
+  m.P = 1; m.exchange = DA_EXCHANGE_ROWS; m.devs.clear();
+  if (o) {
+    if (o->struct_size < (uint32_t)offsetof(da_opts, phase_ms)) return fail(DA_ERR_BAD_ARG, "da_opts.struct_size is not set (sizeof(da_opts))");
+    if (o->n_devices < 0 || (o->n_devices > 0 && !o->devices)) return fail(DA_ERR_BAD_ARG, "bad device list");
+    if (o->exchange != DA_EXCHANGE_ROWS && o->exchange != DA_EXCHANGE_ALLGATHER && o->exchange != DA_EXCHANGE_PEERCOPY)
+      return fail(DA_ERR_BAD_ARG, "unknown exchange mode %d", o->exchange);
+    m.exchange = o->exchange;
+    for (int i = 0; i < o->n_devices; ++i) m.devs.push_back(o->devices[i]);
+  }
+  int rc = require_device();
+  if (rc != DA_OK) return rc;
+  int cnt = 0;
+  DA_HIP_TRY(hipGetDeviceCount(&cnt));
+  if (m.devs.empty()) { int cur = 0; DA_HIP_TRY(hipGetDevice(&cur)); m.devs.push_back(cur); }
+  for (size_t i = 0; i < m.devs.size(); ++i) {
+    if (m.devs[i] < 0 || m.devs[i] >= cnt) return fail(DA_ERR_BAD_ARG, "device %d not present (%d visible)", m.devs[i], cnt);
+    if (m.exchange == DA_EXCHANGE_ALLGATHER)          // RCCL refuses two ranks on one GPU; the other modes allow it (tests on a 1-GPU box)
+      for (size_t j = 0; j < i; ++j)
+        if (m.devs[j] == m.devs[i]) return fail(DA_ERR_BAD_ARG, "device %d listed twice (not allowed with DA_EXCHANGE_ALLGATHER)", m.devs[i]);
+  }
+  m.P = (int)m.devs.size();
+  m.rc.assign(m.P, DA_OK); m.msg.assign(m.P, ""); m.block.assign(m.P, nullptr);
+  m.ms.assign(m.P, std::array<double, PH_COUNT>{});
+  m.bar.reset(new StatusBarrier(m.P));
+  if (m.exchange == DA_EXCHANGE_ALLGATHER) {
+    std::lock_guard<std::mutex> g(rccl_mutex());
+    if (!rccl().load()) return fail(DA_ERR_UNSUPPORTED, "DA_EXCHANGE_ALLGATHER needs RCCL: %s", rccl().why.c_str());
+    m.comms.assign(m.P, nullptr);
+    const ncclResult_t r = rccl().CommInitAll(m.comms.data(), m.P, m.devs.data());
+    if (r != ncclSuccess) { m.comms.clear(); return fail(DA_ERR_HIP, "ncclCommInitAll failed: %s", rccl().GetErrorString(r)); }
+  }
+  return DA_OK;
+}
+
+void destroy_comms(Multi &m) {
+  for (auto c : m.comms) if (c) (void)rccl().CommDestroy(c);
+  m.comms.clear();
+}
+
+// direct xGMI reads of the peers' blocks (PEERCOPY); without it hipMemcpyPeer stages through the host
+void enable_peer_access(const Multi &m, int p) {
+  for (int q = 0; q < m.P; ++q)
+    if (m.devs[q] != m.devs[p]) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, m.devs[p], m.devs[q]) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(m.devs[q], 0);
+        if (e != hipSuccess) (void)hipGetLastError();   // already enabled: fine
+      }
+    }
+}
+
+// run body(p) on one host thread per rank; the first failing rank's status / message become the caller's
+template <typename F> int run_ranks(Multi &m, const da_opts *o, F body) {
+  const double t0 = now_ms();
+  auto one = [&](int p) {
+    int rc = DA_OK;
+    if (hipSetDevice(m.devs[p]) != hipSuccess) rc = fail(DA_ERR_HIP, "hipSetDevice(%d) failed", m.devs[p]);
+    if (rc == DA_OK && m.exchange == DA_EXCHANGE_PEERCOPY) enable_peer_access(m, p);
+    if (rc == DA_OK) rc = body(p);
+    m.rc[p] = rc;
+    if (rc != DA_OK) m.msg[p] = last_error_ref();
+  };
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (m.P == 1) one(0);
+  else {
+    std::vector<std::thread> th;
+    for (int p = 0; p < m.P; ++p) th.emplace_back(one, p);
+    for (auto &t : th) t.join();
+  }
+  (void)hipSetDevice(cur);
+  destroy_comms(m);
+  if (o && o->struct_size >= sizeof(da_opts) && o->phase_ms) {
+    for (int k = 0; k < PH_COUNT; ++k) {
+      double mx = 0.0;
+      for (int p = 0; p < m.P; ++p) mx = std::max(mx, m.ms[p][k]);
+      o->phase_ms[k] = mx;
+    }
+    o->phase_ms[PH_TOTAL] = now_ms() - t0;
+  }
+  for (int p = 0; p < m.P; ++p)
+    if (m.rc[p] != DA_OK) { last_error_ref() = m.msg[p]; return m.rc[p]; }
+  return DA_OK;
+}
+
+// the exchange step of the sharded modes: my block (bytes) -> gathered[P][bytes] on this rank's device
+int exchange_blocks(Multi &m, int p, const void *mine, size_t bytes, void *gathered) {
+  if (m.exchange == DA_EXCHANGE_ALLGATHER) {
+    const ncclResult_t r = rccl().AllGather(mine, gathered, bytes, ncclUint8, m.comms[p], nullptr);
+    if (r != ncclSuccess) return fail(DA_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString(r));
+    DA_HIP_TRY(hipStreamSynchronize(nullptr));
+    return DA_OK;
+  }
+  // PEERCOPY: every peer's block is complete (the barrier before this call); read them all, concurrently
+  for (int q = 0; q < m.P; ++q) {
+    char *dst = static_cast<char *>(gathered) + (size_t)q * bytes;
+    if (m.devs[q] == m.devs[p]) DA_HIP_TRY(hipMemcpyAsync(dst, m.block[q], bytes, hipMemcpyDeviceToDevice, nullptr));
+    else DA_HIP_TRY(hipMemcpyPeerAsync(dst, m.devs[p], m.block[q], m.devs[q], bytes, nullptr));
+  }
+  DA_HIP_TRY(hipStreamSynchronize(nullptr));
+  return DA_OK;
+}
+
+}  // namespace
+}  // namespace da
+
+extern "C" {
+
+int da_rccl_available(void) {
+  std::lock_guard<std::mutex> g(rccl_mutex());
+  return rccl().load() ? 1 : 0;
+}
+
+int da_similarity_mh_opts(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                          const uint32_t *seeds, double *out, const da_opts *opts) {
+  int rc = validate_mh(n, k, n_hash);
+  if (rc != DA_OK) return rc;
+  if (!residues || !seeds || !out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (n_hash > 65535) return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
+  int64_t total, max_len;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  Multi m;
+  if ((rc = parse_opts(opts, m)) != DA_OK) return rc;
+  const int vbits = std::max(8, 32 - __builtin_clz((unsigned)n_hash));
+  const ShardGeom sg = shard_geom(n, m.P, 128);
+  const size_t packed = (size_t)shard_packed_bytes(sg, vbits);
+  return run_ranks(m, opts, [&](int p) -> int {
+    int rc = DA_OK;
+    bool ok;
+    double t = now_ms();
+    DeviceInput in;
+    DevBuf sig, planes, local, pk, gathered, dout;
+    int bits = 32;
+    const int64_t lds = sig_ld_for(n_hash);
+    int64_t r0, r1;
+    row_split(n, m.P, p, &r0, &r1);
+    do {   // setup: upload + K1 + K1b on this device
+      if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) break;
+      if ((rc = sig.alloc((size_t)n * lds * 4)) != DA_OK) break;
+      if ((rc = planes.alloc((size_t)mh_planes_words(n, n_hash) * 4)) != DA_OK) break;
+      if ((rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash, in.seeds.as<uint32_t>(),
+                                          sig.as<uint32_t>(), lds, nullptr)) != DA_OK) break;
+      DevBuf work;
+      const size_t wb = mh_planes_workspace_bytes(n, n_hash);
+      if ((rc = work.alloc(wb)) != DA_OK) break;
+      if ((rc = build_planes(sig.as<uint32_t>(), lds, n, n_hash, 0, work.p, wb, planes.as<uint32_t>(), &bits, nullptr)) != DA_OK) break;
+      if (hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(DA_ERR_HIP, "stream synchronisation failed");
+    } while (0);
+    m.ms[p][PH_SETUP] = now_ms() - t;
+    if (m.exchange == DA_EXCHANGE_ROWS) {
+      if (rc != DA_OK || r1 <= r0) return rc;
+      const int64_t blk = rows_per_block(n, sizeof(double));
+      if ((rc = dout.alloc((size_t)std::min(blk, r1 - r0) * (size_t)n * sizeof(double))) != DA_OK) return rc;
+      for (int64_t b0 = r0; b0 < r1 && rc == DA_OK; b0 += blk) {
+        const int64_t b1 = std::min(r1, b0 + blk);
+        t = now_ms();
+        if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, b0, b1, false, DA_OUT_F64, dout.p, n, nullptr, bits)) != DA_OK) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = fail(DA_ERR_HIP, "compare kernel failed"); break; }
+        m.ms[p][PH_COMPUTE] += now_ms() - t;
+        t = now_ms();
+        rc = d2h_pipelined(out + (size_t)b0 * (size_t)n, dout.p, (size_t)(b1 - b0) * (size_t)n * sizeof(double));
+        m.ms[p][PH_D2H] += now_ms() - t;
+      }
+      return rc;
+    }
+    // sharded modes: cyclic upper-triangle tiles -> packed block -> exchange -> full matrix on this device
+    t = now_ms();
+    if (rc == DA_OK) do {
+      if ((rc = local.alloc((size_t)sg.rows * (size_t)sg.W * 2)) != DA_OK) break;
+      if ((rc = pk.alloc(packed)) != DA_OK) break;
+      if ((rc = gathered.alloc(packed * (size_t)m.P)) != DA_OK) break;
+      if ((rc = dout.alloc((size_t)n * (size_t)n * sizeof(double))) != DA_OK) break;
+      if (hipMemsetAsync(local.p, 0, (size_t)sg.rows * (size_t)sg.W * 2, nullptr) != hipSuccess) { rc = fail(DA_ERR_HIP, "hipMemsetAsync failed"); break; }
+      if ((int64_t)p * 128 < n)
+        if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, (int64_t)p * 128, n, false, DA_OUT_COMPACT, local.p, sg.W, nullptr,
+                                    bits, m.P, true, sg.Q, sg.W)) != DA_OK) break;
+      if ((rc = launch_pack_shard(local.as<uint16_t>(), sg.W, sg, vbits, pk.as<uint8_t>(), nullptr)) != DA_OK) break;
+      if (hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(DA_ERR_HIP, "shard compare failed");
+    } while (0);
+    m.ms[p][PH_COMPUTE] = now_ms() - t;
+    m.block[p] = pk.p;
+    ok = m.bar->arrive(rc == DA_OK);                 // every block is complete (and nobody failed) before anyone exchanges
+    if (!ok) return rc;
+    t = now_ms();
+    rc = exchange_blocks(m, p, pk.p, packed, gathered.p);
+    m.ms[p][PH_EXCHANGE] = now_ms() - t;
+    ok = m.bar->arrive(rc == DA_OK);                 // peers have finished reading my block before it is freed
+    if (!ok) return rc;
+    t = now_ms();
+    if ((rc = launch_finalize_packed(gathered.as<uint8_t>(), sg, vbits, n_hash, dout.as<double>(), n, nullptr)) != DA_OK) return rc;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(DA_ERR_HIP, "finalize kernel failed");
+    m.ms[p][PH_FINALIZE] = now_ms() - t;
+    t = now_ms();
+    if (r1 > r0) rc = d2h_pipelined(out + (size_t)r0 * (size_t)n, dout.as<double>() + (size_t)r0 * (size_t)n, (size_t)(r1 - r0) * (size_t)n * sizeof(double));
+    m.ms[p][PH_D2H] = now_ms() - t;
+    return rc;
+  });
+}
+
+int da_similarity_nw_opts(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name, int gap_open,
+                          int gap_ext, double *out, const da_opts *opts) {
+  const int mid = da_matrix_id(matrix_name);          // reference :338 -> :190-206, before anything else
+  if (mid < 0) return DA_ERR_BAD_MATRIX;
+  if (n <= 0) return DA_OK;                            // reference returns a 0x0 matrix
+  if (!residues || !out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  int64_t total, max_len;
+  int rc;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  if ((rc = nw_validate(residues, offsets, n)) != DA_OK) return rc;
+  Multi m;
+  if ((rc = parse_opts(opts, m)) != DA_OK) return rc;
+  if (m.exchange != DA_EXCHANGE_ROWS && max_len > 64) {
+    destroy_comms(m);
+    return fail(DA_ERR_UNSUPPORTED, "the sharded NW exchange works on uint16 codes of sequences up to 64 residues (longest here: %lld); "
+                                    "use DA_EXCHANGE_ROWS", (long long)max_len);
+  }
+  const ShardGeom sg = shard_geom(n, m.P, 64);
+  const size_t blk_bytes = (size_t)sg.rows * (size_t)sg.W * 2;
+  return run_ranks(m, opts, [&](int p) -> int {
+    int rc = DA_OK;
+    bool ok;
+    double t = now_ms();
+    DeviceInput in;
+    DevBuf codes, bad, local, gathered, dout;
+    int64_t r0, r1;
+    row_split(n, m.P, p, &r0, &r1);
+    do {
+      if ((rc = in.upload(residues, offsets, n, total, nullptr, 0)) != DA_OK) break;
+      if ((rc = codes.alloc((size_t)total)) != DA_OK) break;
+      if ((rc = bad.alloc(sizeof(int32_t))) != DA_OK) break;
+      if (hipMemsetAsync(bad.p, 0, sizeof(int32_t), nullptr) != hipSuccess) { rc = fail(DA_ERR_HIP, "hipMemsetAsync failed"); break; }
+      rc = launch_nw_encode(in.res.as<uint8_t>(), total, codes.as<uint8_t>(), bad.as<int32_t>(), nullptr);
+    } while (0);
+    m.ms[p][PH_SETUP] = now_ms() - t;
+    if (m.exchange == DA_EXCHANGE_ROWS) {
+      if (rc != DA_OK || r1 <= r0) return rc;
+      const int64_t blk = rows_per_block(n, sizeof(double));
+      if ((rc = dout.alloc((size_t)std::min(blk, r1 - r0) * (size_t)n * sizeof(double))) != DA_OK) return rc;
+      for (int64_t b0 = r0; b0 < r1 && rc == DA_OK; b0 += blk) {
+        const int64_t b1 = std::min(r1, b0 + blk);
+        t = now_ms();
+        if ((rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, b0, b1, false, DA_OUT_F64,
+                            dout.p, n, nullptr, 0, nullptr)) != DA_OK) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = fail(DA_ERR_HIP, "NW kernel failed"); break; }
+        m.ms[p][PH_COMPUTE] += now_ms() - t;
+        t = now_ms();
+        rc = d2h_pipelined(out + (size_t)b0 * (size_t)n, dout.p, (size_t)(b1 - b0) * (size_t)n * sizeof(double));
+        m.ms[p][PH_D2H] += now_ms() - t;
+      }
+      return rc;
+    }
+    t = now_ms();
+    if (rc == DA_OK) do {
+      if ((rc = local.alloc(blk_bytes)) != DA_OK) break;
+      if ((rc = gathered.alloc(blk_bytes * (size_t)m.P)) != DA_OK) break;
+      if ((rc = dout.alloc((size_t)n * (size_t)n * sizeof(double))) != DA_OK) break;
+      if (hipMemsetAsync(local.p, 0, blk_bytes, nullptr) != hipSuccess) { rc = fail(DA_ERR_HIP, "hipMemsetAsync failed"); break; }
+      if ((rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, 0, n, false, DA_OUT_COMPACT,
+                          local.p, sg.W, nullptr, 0, nullptr, p, m.P)) != DA_OK) break;
+      if (hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(DA_ERR_HIP, "NW shard kernel failed");
+    } while (0);
+    m.ms[p][PH_COMPUTE] = now_ms() - t;
+    m.block[p] = local.p;
+    ok = m.bar->arrive(rc == DA_OK);
+    if (!ok) return rc;
+    t = now_ms();
+    rc = exchange_blocks(m, p, local.p, blk_bytes, gathered.p);
+    m.ms[p][PH_EXCHANGE] = now_ms() - t;
+    ok = m.bar->arrive(rc == DA_OK);
+    if (!ok) return rc;
+    t = now_ms();
+    if ((rc = launch_finalize_sharded(gathered.as<uint16_t>(), sg.W, sg, true, 0, dout.as<double>(), n, nullptr)) != DA_OK) return rc;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(DA_ERR_HIP, "finalize kernel failed");
+    m.ms[p][PH_FINALIZE] = now_ms() - t;
+    t = now_ms();
+    if (r1 > r0) rc = d2h_pipelined(out + (size_t)r0 * (size_t)n, dout.as<double>() + (size_t)r0 * (size_t)n, (size_t)(r1 - r0) * (size_t)n * sizeof(double));
+    m.ms[p][PH_D2H] = now_ms() - t;
+    return rc;
+  });
 }
 
 }  // extern "C"

@@ -88,6 +88,37 @@ uint32_t da_random_seed(void);
 int da_similarity_mh(const uint8_t *residues, const int64_t *offsets, int64_t n,
                      int k, int n_hash, const uint32_t *seeds, double *out);
 
+/* ---- the same two bodies on several GPUs of the node, ONE process (SURVEY 8(b) "da_opts", 8(e)) ----
+ * opts == NULL behaves like da_similarity_mh / da_similarity_nw on the current device.  With a device list, a host
+ * thread per device runs the pipeline on its GPU and copies ITS rows of the result into `out` (P PCIe links instead
+ * of one).  `exchange` selects how the pair space is split and reassembled:
+ *   DA_EXCHANGE_ROWS       device p computes the contiguous row block it copies out; no device-to-device traffic
+ *                          (default; the same device may be listed more than once);
+ *   DA_EXCHANGE_ALLGATHER  cyclic upper-triangle shards (da_dev_*_shard), ONE ncclAllGather over xGMI (RCCL,
+ *                          ncclCommInitAll on the list), mirror + widen to the full matrix on every device;
+ *   DA_EXCHANGE_PEERCOPY   the same shards, exchanged by concurrent hipMemcpyPeerAsync reads of every peer's block
+ *                          (xGMI is point-to-point: all links at once; no RCCL needed).
+ * NW with an exchange needs sequences of <= 64 residues (uint16 shard codes); ROWS has the limits of da_similarity_nw.
+ * phase_ms (optional, DA_PHASE_COUNT doubles): per phase the maximum over devices, in ms --
+ *   [0] upload + signatures/codes  [1] compare / NW  [2] exchange  [3] finalize  [4] device-to-host  [5] whole call.
+ * The R glue builds this struct from options(DynaAlign.devices = , DynaAlign.exchange = ) (r_glue/). */
+enum da_exchange { DA_EXCHANGE_ROWS = 0, DA_EXCHANGE_ALLGATHER = 1, DA_EXCHANGE_PEERCOPY = 2 };
+#define DA_PHASE_COUNT 6
+typedef struct da_opts {
+  uint32_t struct_size;      /* sizeof(da_opts) -- lets the struct grow without breaking callers */
+  int32_t n_devices;         /* 0: the current device */
+  const int32_t *devices;    /* HIP device ordinals */
+  int32_t exchange;          /* enum da_exchange */
+  uint32_t reserved;         /* 0 */
+  double *phase_ms;          /* NULL or DA_PHASE_COUNT doubles (out) */
+} da_opts;
+int da_similarity_mh_opts(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                          int k, int n_hash, const uint32_t *seeds, double *out, const da_opts *opts);
+int da_similarity_nw_opts(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                          const char *matrix_name, int gap_open, int gap_ext, double *out, const da_opts *opts);
+/* 1 when librccl can be bound in this process (DA_EXCHANGE_ALLGATHER usable), else 0. */
+int da_rccl_available(void);
+
 /* The signature matrix alone (src/minHash.cpp:140-157): sig_out[n][n_hash]. */
 int da_minhash_signatures(const uint8_t *residues, const int64_t *offsets, int64_t n,
                           int k, int n_hash, const uint32_t *seeds, uint32_t *sig_out);
