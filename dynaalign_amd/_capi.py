@@ -47,6 +47,10 @@ SIGNATURES = {
     "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "da_similarity_mh_edges": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, C.c_double, _vp, _vp, _i64, _vp, _vp, _vp]),
     "da_similarity_nw_edges": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, C.c_double, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "da_similarity_mh_edges_begin": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, C.c_double, _vp, _vp, _vp]),
+    "da_similarity_nw_edges_begin": (_i32, [_vp, _vp, _i64, C.c_char_p, _i32, _i32, C.c_double, _vp, _vp, _vp]),
+    "da_edges_fetch": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "da_edges_free": (None, [_vp]),
     "da_quantile_type7": (_i32, [_vp, _vp, _i32, C.c_double, _vp]),
     "da_dev_upper_histogram": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "da_dev_extract_edges": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),

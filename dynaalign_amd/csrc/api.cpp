@@ -566,9 +566,15 @@ static int nw_validate(const uint8_t *residues, const int64_t *offsets, int64_t 
 //   threshold <- quantile(S[upper.tri(S)], thresh_p)   (R type 7, R/clusterbreak.R:219)
 //   S[S < threshold] <- 0; a zero weight is no edge     (:221; igraph, weighted = TRUE)
 // The diagonal (1.0) always survives.  Edges come back sorted by (i, j).
+struct EdgeSet {
+  double threshold = 0.0;
+  std::vector<int32_t> i, j;
+  std::vector<double> w;
+};
+
 static int edges_from_counts(const uint16_t *d_cnt, int64_t n, int nbins, const unsigned long long *d_hist,
-                             const std::vector<double> &values, double thresh_p, double *threshold_out,
-                             int64_t *n_edges_out, int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+                             const std::vector<double> &values, double thresh_p, bool want_edges, EdgeSet &es,
+                             int64_t *n_edges_out) {
   int rc;
   std::vector<uint64_t> h(nbins);
   DA_HIP_TRY(hipMemcpy(h.data(), d_hist, (size_t)nbins * 8, hipMemcpyDeviceToHost));
@@ -581,7 +587,7 @@ static int edges_from_counts(const uint16_t *d_cnt, int64_t n, int nbins, const 
   for (int b = 0; b < nbins; ++b) { hs[b] = h[order[b]]; vs[b] = values[order[b]]; }
   double thr;
   if ((rc = da_quantile_type7(hs.data(), vs.data(), nbins, thresh_p, &thr)) != DA_OK) return rc;
-  *threshold_out = thr;
+  es.threshold = thr;
   std::vector<uint8_t> kp(nbins);
   int64_t n_edges = n;                                                       // the diagonal (1.0) always survives
   for (int b = 0; b < nbins; ++b) {
@@ -589,11 +595,7 @@ static int edges_from_counts(const uint16_t *d_cnt, int64_t n, int nbins, const 
     if (kp[b]) n_edges += (int64_t)h[b];
   }
   *n_edges_out = n_edges;
-  if (!ei && !ej && !ew) return DA_OK;                                       // size query
-  if (!ei || !ej || !ew) return fail(DA_ERR_BAD_ARG, "NULL edge buffer");
-  if (capacity < n_edges) return fail(DA_ERR_BAD_ARG, "edge buffers hold %lld entries, %lld needed", (long long)capacity,
-                                      (long long)n_edges);
-  if (n_edges == 0) return DA_OK;
+  if (!want_edges || n_edges == 0) return DA_OK;
   DevBuf keep, cnt_edges, di, dj, dv;
   if ((rc = keep.alloc((size_t)nbins)) != DA_OK) return rc;
   if ((rc = cnt_edges.alloc(8)) != DA_OK) return rc;
@@ -619,10 +621,26 @@ static int edges_from_counts(const uint16_t *d_cnt, int64_t n, int nbins, const 
   std::sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) {
     return hi_[a] != hi_[b] ? hi_[a] < hi_[b] : hj_[a] < hj_[b];
   });
+  es.i.resize(n_edges); es.j.resize(n_edges); es.w.resize(n_edges);
   for (int64_t e = 0; e < n_edges; ++e) {
-    ei[e] = hi_[ord[e]];
-    ej[e] = hj_[ord[e]];
-    ew[e] = values[hv_[ord[e]]];
+    es.i[e] = hi_[ord[e]];
+    es.j[e] = hj_[ord[e]];
+    es.w[e] = values[hv_[ord[e]]];
+  }
+  return DA_OK;
+}
+
+// legacy calling convention of the *_edges entry points on top of an EdgeSet: size query (all buffers NULL) or fill
+static int edges_deliver(const EdgeSet &es, int64_t n_edges, double *threshold_out, int64_t *n_edges_out, int64_t capacity,
+                         int32_t *ei, int32_t *ej, double *ew) {
+  *threshold_out = es.threshold;
+  *n_edges_out = n_edges;
+  if (!ei && !ej && !ew) return DA_OK;
+  if (capacity < n_edges) return fail(DA_ERR_BAD_ARG, "edge buffers hold %lld entries, %lld needed", (long long)capacity, (long long)n_edges);
+  if (n_edges) {
+    memcpy(ei, es.i.data(), (size_t)n_edges * 4);
+    memcpy(ej, es.j.data(), (size_t)n_edges * 4);
+    memcpy(ew, es.w.data(), (size_t)n_edges * 8);
   }
   return DA_OK;
 }
@@ -630,12 +648,11 @@ static int edges_from_counts(const uint16_t *d_cnt, int64_t n, int nbins, const 
 // similarityNW + clusterbreak's threshold step as an edge list.  The uint16 code (matches << 8 | length)
 // takes few distinct values, so the same histogram / quantile / extraction path as for MinHash applies;
 // value(code) = matches / length with the reference's divide (src/pairwiseSeqAlign.cpp:311).
-int da_similarity_nw_edges(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name,
-                           int gap_open, int gap_ext, double thresh_p, double *threshold_out, int64_t *n_edges_out,
-                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+static int nw_edges_core(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name,
+                         int gap_open, int gap_ext, double thresh_p, bool want_edges, EdgeSet &es, int64_t *n_edges_out) {
   const int mid = da_matrix_id(matrix_name);  // reference :338 -> :190-206, before anything else
   if (mid < 0) return DA_ERR_BAD_MATRIX;
-  if (!residues || !threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (!residues) return fail(DA_ERR_BAD_ARG, "NULL pointer");
   if (n < 2) return fail(DA_ERR_BAD_ARG, "the threshold is a quantile of the strict upper triangle: need >= 2 sequences");
   if (!(thresh_p >= 0.0 && thresh_p <= 1.0)) return fail(DA_ERR_BAD_ARG, "thresh_p must be in [0, 1]");
   int64_t total, max_len;
@@ -668,16 +685,14 @@ int da_similarity_nw_edges(const uint8_t *residues, const int64_t *offsets, int6
     const int ln = b & 255;
     values[b] = ln ? (double)(b >> 8) / (double)ln : 0.0;                   // length 0 cannot occur (no empty sequences)
   }
-  return edges_from_counts(cnt.as<uint16_t>(), n, nbins, hist.as<unsigned long long>(), values, thresh_p, threshold_out,
-                           n_edges_out, capacity, ei, ej, ew);
+  return edges_from_counts(cnt.as<uint16_t>(), n, nbins, hist.as<unsigned long long>(), values, thresh_p, want_edges, es, n_edges_out);
 }
 
-int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
-                           const uint32_t *seeds, double thresh_p, double *threshold_out, int64_t *n_edges_out,
-                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+static int mh_edges_core(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                         const uint32_t *seeds, double thresh_p, bool want_edges, EdgeSet &es, int64_t *n_edges_out) {
   int rc = validate_mh(n, k, n_hash);
   if (rc != DA_OK) return rc;
-  if (!residues || !seeds || !threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (!residues || !seeds) return fail(DA_ERR_BAD_ARG, "NULL pointer");
   if (n < 2) return fail(DA_ERR_BAD_ARG, "the threshold is a quantile of the strict upper triangle: need >= 2 sequences");
   if (!(thresh_p >= 0.0 && thresh_p <= 1.0)) return fail(DA_ERR_BAD_ARG, "thresh_p must be in [0, 1]");
   if (n_hash > 65535) return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
@@ -710,9 +725,74 @@ int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int6
   if ((rc = launch_upper_histogram(cnt.as<uint16_t>(), n, n, nbins, hist.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
   std::vector<double> values(nbins);
   for (int b = 0; b < nbins; ++b) values[b] = (double)b / n_hash;          // src/minHash.cpp:174
-  return edges_from_counts(cnt.as<uint16_t>(), n, nbins, hist.as<unsigned long long>(), values, thresh_p, threshold_out,
-                           n_edges_out, capacity, ei, ej, ew);
+  return edges_from_counts(cnt.as<uint16_t>(), n, nbins, hist.as<unsigned long long>(), values, thresh_p, want_edges, es, n_edges_out);
 }
+
+// ---- public forms.  da_similarity_*_edges: size query (buffers NULL) or fill -- each call runs the whole pipeline.
+// da_similarity_*_edges_begin / da_edges_fetch / da_edges_free: ONE pass; the result waits in a handle until fetched.
+struct da_edges { EdgeSet es; int64_t n_edges = 0; };
+
+int da_similarity_nw_edges(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name,
+                           int gap_open, int gap_ext, double thresh_p, double *threshold_out, int64_t *n_edges_out,
+                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+  if (!threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if ((ei || ej || ew) && (!ei || !ej || !ew)) return fail(DA_ERR_BAD_ARG, "NULL edge buffer");
+  EdgeSet es;
+  int64_t m = 0;
+  int rc = nw_edges_core(residues, offsets, n, matrix_name, gap_open, gap_ext, thresh_p, ei != nullptr, es, &m);
+  if (rc != DA_OK) return rc;
+  return edges_deliver(es, m, threshold_out, n_edges_out, capacity, ei, ej, ew);
+}
+
+int da_similarity_mh_edges(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                           const uint32_t *seeds, double thresh_p, double *threshold_out, int64_t *n_edges_out,
+                           int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+  if (!threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if ((ei || ej || ew) && (!ei || !ej || !ew)) return fail(DA_ERR_BAD_ARG, "NULL edge buffer");
+  EdgeSet es;
+  int64_t m = 0;
+  int rc = mh_edges_core(residues, offsets, n, k, n_hash, seeds, thresh_p, ei != nullptr, es, &m);
+  if (rc != DA_OK) return rc;
+  return edges_deliver(es, m, threshold_out, n_edges_out, capacity, ei, ej, ew);
+}
+
+int da_similarity_mh_edges_begin(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
+                                 const uint32_t *seeds, double thresh_p, da_edges **handle_out, double *threshold_out,
+                                 int64_t *n_edges_out) {
+  if (!handle_out || !threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  *handle_out = nullptr;
+  std::unique_ptr<da_edges> h(new da_edges);
+  int rc = mh_edges_core(residues, offsets, n, k, n_hash, seeds, thresh_p, true, h->es, &h->n_edges);
+  if (rc != DA_OK) return rc;
+  *threshold_out = h->es.threshold;
+  *n_edges_out = h->n_edges;
+  *handle_out = h.release();
+  return DA_OK;
+}
+
+int da_similarity_nw_edges_begin(const uint8_t *residues, const int64_t *offsets, int64_t n, const char *matrix_name,
+                                 int gap_open, int gap_ext, double thresh_p, da_edges **handle_out, double *threshold_out,
+                                 int64_t *n_edges_out) {
+  if (!handle_out || !threshold_out || !n_edges_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  *handle_out = nullptr;
+  std::unique_ptr<da_edges> h(new da_edges);
+  int rc = nw_edges_core(residues, offsets, n, matrix_name, gap_open, gap_ext, thresh_p, true, h->es, &h->n_edges);
+  if (rc != DA_OK) return rc;
+  *threshold_out = h->es.threshold;
+  *n_edges_out = h->n_edges;
+  *handle_out = h.release();
+  return DA_OK;
+}
+
+int da_edges_fetch(const da_edges *h, int64_t capacity, int32_t *ei, int32_t *ej, double *ew) {
+  if (!h || !ei || !ej || !ew) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  double thr;
+  int64_t m;
+  return edges_deliver(h->es, h->n_edges, &thr, &m, capacity, ei, ej, ew);
+}
+
+void da_edges_free(da_edges *h) { delete h; }
+
 
 int64_t da_sig_ld(int n_hash) { return sig_ld_for(n_hash); }
 
@@ -1121,6 +1201,10 @@ int da_similarity_mh_opts(const uint8_t *residues, const int64_t *offsets, int64
   if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
   Multi m;
   if ((rc = parse_opts(opts, m)) != DA_OK) return rc;
+  if (m.P == 1 && m.exchange == DA_EXCHANGE_ROWS)      // one device, nothing to split: the symmetric single-device path
+    return run_ranks(m, opts, [&](int) -> int {
+      return mh_host_common(residues, offsets, n, k, n_hash, seeds, 0, n, DA_OUT_F64, out);
+    });
   const int vbits = std::max(8, 32 - __builtin_clz((unsigned)n_hash));
   const ShardGeom sg = shard_geom(n, m.P, 128);
   const size_t packed = (size_t)shard_packed_bytes(sg, vbits);
@@ -1214,6 +1298,10 @@ int da_similarity_nw_opts(const uint8_t *residues, const int64_t *offsets, int64
     return fail(DA_ERR_UNSUPPORTED, "the sharded NW exchange works on uint16 codes of sequences up to 64 residues (longest here: %lld); "
                                     "use DA_EXCHANGE_ROWS", (long long)max_len);
   }
+  if (m.P == 1 && m.exchange == DA_EXCHANGE_ROWS)
+    return run_ranks(m, opts, [&](int) -> int {
+      return nw_host_common(residues, offsets, n, matrix_name, gap_open, gap_ext, 0, n, out, nullptr, nullptr, nullptr);
+    });
   const ShardGeom sg = shard_geom(n, m.P, 64);
   const size_t blk_bytes = (size_t)sg.rows * (size_t)sg.W * 2;
   return run_ranks(m, opts, [&](int p) -> int {

@@ -22,7 +22,8 @@ import numpy as np
 
 from . import _capi
 
-_OPTIONS = {"seed": None}
+# options(DynaAlign.seed = , DynaAlign.devices = , DynaAlign.exchange = ) of the R glue (r_glue/)
+_OPTIONS = {"seed": None, "devices": None, "exchange": "rows"}
 
 
 def set_option(name, value):
@@ -103,16 +104,48 @@ def _mh_prelude(sequences, k, n_hash, seed):
     return lib, res, off, n, k, n_hash, seeds
 
 
-def similarityMH(sequences, k=4, n_hash=50, *, seed=None):
+def _device_opts(devices, exchange):
+    """da_opts for the multi-device entry points, or None for the plain single-device call"""
+    devices = _OPTIONS["devices"] if devices is None else devices
+    exchange = exchange or _OPTIONS["exchange"] or "rows"
+    if devices is None and os.environ.get("DYNAALIGN_DEVICES"):
+        devices = [int(d) for d in os.environ["DYNAALIGN_DEVICES"].split(",") if d.strip() != ""]
+    if devices is None:
+        return None, None
+    if isinstance(devices, int):
+        devices = [devices]
+    return _capi.make_opts(devices, exchange)
+
+
+last_phase_ms = {}   # phase times of the most recent multi-device call (da_opts.phase_ms), by phase name
+
+
+def _record_phases(keep):
+    last_phase_ms.clear()
+    if keep is not None:
+        last_phase_ms.update(zip(_capi.DA_PHASES, [float(v) for v in keep[1]]))
+
+
+def similarityMH(sequences, k=4, n_hash=50, *, seed=None, devices=None, exchange=None):
     """MinHash-estimated Jaccard similarity of k-mer sets, all pairs.
 
     Mirrors reference ``similarityMH`` (src/minHash.cpp:119-188): errors
     "Input sequences vector cannot be empty" / "'k' must be a positive integer" /
-    "Number of hash functions must be positive" in that order; diagonal 1.0."""
+    "Number of hash functions must be positive" in that order; diagonal 1.0.
+
+    devices= / set_option("devices", [...]) / DYNAALIGN_DEVICES=0,1,..: run on several GPUs of the node from this one
+    process (da_similarity_mh_opts); exchange = "rows" (default), "allgather" (RCCL) or "peercopy"."""
     lib, res, off, n, k, n_hash, seeds = _mh_prelude(sequences, k, n_hash, seed)
     out = np.empty((max(n, 1), max(n, 1)), np.float64)
-    _capi.check(lib.da_similarity_mh(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
-                                     out.ctypes.data))
+    opts, keep = _device_opts(devices, exchange)
+    if opts is None:
+        _capi.check(lib.da_similarity_mh(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
+                                         out.ctypes.data))
+    else:
+        import ctypes
+        _capi.check(lib.da_similarity_mh_opts(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
+                                              out.ctypes.data, ctypes.addressof(opts)))
+    _record_phases(keep)
     return SimilarityMatrix(out[:n, :n])
 
 
@@ -135,20 +168,28 @@ def mh_counts(sequences, k=4, n_hash=50, *, seed=None, row_begin=0, row_end=None
     return out[:max(row_end - row_begin, 0), :n]
 
 
-def similarityNW(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4):
+def similarityNW(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4, *, devices=None, exchange=None):
     """Fraction identity (matches / alignment length) of the reference's
     affine-gap global alignment, all pairs.
 
     Mirrors reference ``similarityNW`` (src/pairwiseSeqAlign.cpp:331-365): no input
     validation beyond "Invalid substitution matrix name: %s" and the lazily raised
-    "Invalid amino acid in sequence1/2: %c"; n == 0 gives a 0 x 0 matrix."""
+    "Invalid amino acid in sequence1/2: %c"; n == 0 gives a 0 x 0 matrix.
+    devices= / exchange=: as for similarityMH (da_similarity_nw_opts)."""
     lib = _capi.load()
     res, off = pack_sequences(sequences)
     n = len(off) - 1
     out = np.empty((max(n, 1), max(n, 1)), np.float64)
     name = matrixName.encode("latin-1") if isinstance(matrixName, str) else bytes(matrixName)
-    _capi.check(lib.da_similarity_nw(res.ctypes.data, off.ctypes.data, n, name, _as_int(gapOpen, "gapOpen"),
-                                     _as_int(gapExt, "gapExt"), out.ctypes.data))
+    opts, keep = _device_opts(devices, exchange)
+    if opts is None:
+        _capi.check(lib.da_similarity_nw(res.ctypes.data, off.ctypes.data, n, name, _as_int(gapOpen, "gapOpen"),
+                                         _as_int(gapExt, "gapExt"), out.ctypes.data))
+    else:
+        import ctypes
+        _capi.check(lib.da_similarity_nw_opts(res.ctypes.data, off.ctypes.data, n, name, _as_int(gapOpen, "gapOpen"),
+                                              _as_int(gapExt, "gapExt"), out.ctypes.data, ctypes.addressof(opts)))
+    _record_phases(keep)
     return SimilarityMatrix(out[:n, :n])
 
 
@@ -192,15 +233,24 @@ def similarityMH_edges(sequences, k=4, n_hash=50, thresh_p=0.8, *, seed=None):
     but returns only ``(threshold, i, j, weight)`` -- the surviving entries with i <= j (0-based, sorted),
     never the dense matrix."""
     lib, res, off, n, k, n_hash, seeds = _mh_prelude(sequences, k, n_hash, seed)
+    return _edges_one_pass(lambda h, thr, cnt: lib.da_similarity_mh_edges_begin(
+        res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data, float(thresh_p), h, thr, cnt))
+
+
+def _edges_one_pass(begin):
+    """*_edges_begin -> da_edges_fetch -> da_edges_free: the pipeline runs once (the size-query form runs it twice)"""
+    import ctypes
+    lib = _capi.load()
+    handle = ctypes.c_void_p()
     thr = np.zeros(1, np.float64)
     cnt = np.zeros(1, np.int64)
-    _capi.check(lib.da_similarity_mh_edges(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
-                                           float(thresh_p), thr.ctypes.data, cnt.ctypes.data, 0, None, None, None))
-    m = int(cnt[0])
-    ei, ej, ew = np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.float64)
-    _capi.check(lib.da_similarity_mh_edges(res.ctypes.data, off.ctypes.data, n, k, n_hash, seeds.ctypes.data,
-                                           float(thresh_p), thr.ctypes.data, cnt.ctypes.data, m, ei.ctypes.data,
-                                           ej.ctypes.data, ew.ctypes.data))
+    _capi.check(begin(ctypes.addressof(handle), thr.ctypes.data, cnt.ctypes.data))
+    try:
+        m = int(cnt[0])
+        ei, ej, ew = np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.float64)
+        _capi.check(lib.da_edges_fetch(handle, m, ei.ctypes.data, ej.ctypes.data, ew.ctypes.data))
+    finally:
+        lib.da_edges_free(handle)
     return float(thr[0]), ei[:m], ej[:m], ew[:m]
 
 
@@ -213,13 +263,5 @@ def similarityNW_edges(sequences, matrixName="BLOSUM62", gapOpen=10, gapExt=4, t
     n = len(off) - 1
     name = matrixName.encode("latin-1") if isinstance(matrixName, str) else bytes(matrixName)
     go, ge = _as_int(gapOpen, "gapOpen"), _as_int(gapExt, "gapExt")
-    thr = np.zeros(1, np.float64)
-    cnt = np.zeros(1, np.int64)
-    _capi.check(lib.da_similarity_nw_edges(res.ctypes.data, off.ctypes.data, n, name, go, ge, float(thresh_p),
-                                           thr.ctypes.data, cnt.ctypes.data, 0, None, None, None))
-    m = int(cnt[0])
-    ei, ej, ew = np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.int32), np.empty(max(m, 1), np.float64)
-    _capi.check(lib.da_similarity_nw_edges(res.ctypes.data, off.ctypes.data, n, name, go, ge, float(thresh_p),
-                                           thr.ctypes.data, cnt.ctypes.data, m, ei.ctypes.data, ej.ctypes.data,
-                                           ew.ctypes.data))
-    return float(thr[0]), ei[:m], ej[:m], ew[:m]
+    return _edges_one_pass(lambda h, thr, cnt: lib.da_similarity_nw_edges_begin(
+        res.ctypes.data, off.ctypes.data, n, name, go, ge, float(thresh_p), h, thr, cnt))

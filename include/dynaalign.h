@@ -274,6 +274,19 @@ int da_similarity_nw_edges(const uint8_t *residues, const int64_t *offsets, int6
                            const char *matrix_name, int gap_open, int gap_ext, double thresh_p,
                            double *threshold_out, int64_t *n_edges_out,
                            int64_t capacity, int32_t *ei, int32_t *ej, double *ew);
+/* One-pass form of the two functions above: *_begin runs the pipeline ONCE and parks the sorted edge list in a
+ * handle; the caller sizes its vectors from n_edges_out, copies with da_edges_fetch and releases the handle with
+ * da_edges_free (the size-query-then-fill convention above runs the whole pipeline twice).  The handle is the one
+ * library-owned object of this ABI; it holds host memory only. */
+typedef struct da_edges da_edges;
+int da_similarity_mh_edges_begin(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                                 int k, int n_hash, const uint32_t *seeds, double thresh_p,
+                                 da_edges **handle_out, double *threshold_out, int64_t *n_edges_out);
+int da_similarity_nw_edges_begin(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                                 const char *matrix_name, int gap_open, int gap_ext, double thresh_p,
+                                 da_edges **handle_out, double *threshold_out, int64_t *n_edges_out);
+int da_edges_fetch(const da_edges *handle, int64_t capacity, int32_t *ei, int32_t *ej, double *ew);
+void da_edges_free(da_edges *handle);
 /* R's quantile(x, p, type = 7) of the multiset {values[b] repeated hist[b] times},
  * values ascending (host arithmetic, no device needed). */
 int da_quantile_type7(const uint64_t *hist, const double *values, int nbins, double p, double *q_out);

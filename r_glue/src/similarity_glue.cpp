@@ -2,16 +2,21 @@
 // src/minHash.cpp (similarityMH, :119-188) and src/pairwiseSeqAlign.cpp
 // (similarityNW, :331-365) with calls into libdynaalign_hip.so (include/dynaalign.h).
 //
-// Drop-in recipe: delete those two files from the reference's src/,
-// add this file and the Makevars next to it, run Rcpp::compileAttributes() (or keep the
-// reference's generated src/RcppExports.cpp and R/RcppExports.R unchanged -- the exported
-// signatures below are identical, so the generated code is byte-identical too).
+// Drop-in recipe: delete those two files from the reference's src/, add this
+// file and the Makevars next to it and re-run Rcpp::compileAttributes().  The two exported
+// signatures the reference already has (similarityMH, similarityNW) are kept verbatim, so their
+// generated shims come out byte-identical; the two ADDED exports (similarityMH_edges,
+// similarityNW_edges) get new shims in src/RcppExports.cpp + R/RcppExports.R and need
+// `export(similarityMH_edges)` / `export(similarityNW_edges)` in NAMESPACE (roxygen writes them
+// from the @export tags below).  Without compileAttributes() only the two original functions
+// are callable.
 //
 // NOT compiled in the build container (R and Rcpp are absent there); it is the binding a
 // maintainer adds.  Everything it calls is exercised through the same C ABI by
 // dynaalign_amd/similarity.py and the test-suite.
 #include <Rcpp.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -61,10 +66,68 @@ uint32_t hash_seed() {
   Environment base = Environment::base_env();
   Function getOption = base["getOption"];
   SEXP opt = getOption("DynaAlign.seed");
-  if (!Rf_isNull(opt)) return (uint32_t)as<double>(opt);
-  if (const char *e = std::getenv("DYNAALIGN_SEED")) return (uint32_t)std::strtoul(e, nullptr, 10);
+  if (!Rf_isNull(opt)) {
+    // reduce modulo 2^32 through a 64-bit integer: a direct double -> uint32_t cast of a negative or
+    // > 2^32 value is undefined behaviour
+    const double d = std::floor(as<double>(opt));
+    if (!(std::fabs(d) < 9.0e15)) Rcpp::stop("options(DynaAlign.seed) must be a finite integer");
+    return (uint32_t)((uint64_t)(int64_t)d & 0xffffffffu);
+  }
+  if (const char *e = std::getenv("DYNAALIGN_SEED")) return (uint32_t)(std::strtoull(e, nullptr, 10) & 0xffffffffu);
   return da_random_seed();
 }
+
+// options(DynaAlign.devices = c(0L, 1L, ...)) -- HIP device ordinals this ONE R process drives (a host thread per
+// device inside the library) -- and options(DynaAlign.exchange = "rows" | "allgather" | "peercopy").  Unset: the
+// current device, exactly as before.  DYNAALIGN_DEVICES=0,1,.. is the environment form.
+struct DeviceOpts {
+  std::vector<int32_t> devices;
+  da_opts opts;
+  bool set = false;
+  DeviceOpts() {
+    Environment base = Environment::base_env();
+    Function getOption = base["getOption"];
+    SEXP dv = getOption("DynaAlign.devices");
+    if (!Rf_isNull(dv)) {
+      IntegerVector v = as<IntegerVector>(dv);
+      devices.assign(v.begin(), v.end());
+      set = true;
+    } else if (const char *e = std::getenv("DYNAALIGN_DEVICES")) {
+      for (const char *p = e; *p;) {
+        char *end = nullptr;
+        const long d = std::strtol(p, &end, 10);
+        if (end == p) break;
+        devices.push_back((int32_t)d);
+        p = (*end == ',') ? end + 1 : end;
+      }
+      set = !devices.empty();
+    }
+    int exchange = DA_EXCHANGE_ROWS;
+    SEXP ex = getOption("DynaAlign.exchange");
+    if (!Rf_isNull(ex)) {
+      const std::string x = as<std::string>(ex);
+      if (x == "rows") exchange = DA_EXCHANGE_ROWS;
+      else if (x == "allgather") exchange = DA_EXCHANGE_ALLGATHER;
+      else if (x == "peercopy") exchange = DA_EXCHANGE_PEERCOPY;
+      else Rcpp::stop("options(DynaAlign.exchange) must be \"rows\", \"allgather\" or \"peercopy\"");
+    }
+    opts.struct_size = (uint32_t)sizeof(da_opts);
+    opts.n_devices = (int32_t)devices.size();
+    opts.devices = devices.empty() ? nullptr : devices.data();
+    opts.exchange = exchange;
+    opts.reserved = 0;
+    opts.phase_ms = nullptr;
+  }
+  const da_opts *get() const { return set ? &opts : nullptr; }   // NULL = da_similarity_mh / _nw on the current device
+};
+
+struct EdgesHandle {   // da_edges_free on scope exit
+  da_edges *h;
+  explicit EdgesHandle(da_edges *p) : h(p) {}
+  ~EdgesHandle() { da_edges_free(h); }
+  EdgesHandle(const EdgesHandle &) = delete;
+  EdgesHandle &operator=(const EdgesHandle &) = delete;
+};
 
 }  // namespace
 
@@ -84,10 +147,11 @@ NumericMatrix similarityMH(CharacterVector sequences, int k = 4, int n_hash = 50
   std::vector<uint32_t> seeds(n_hash > 0 ? n_hash : 1);
   if (n_hash > 0) check(da_hash_family_seeds(hash_seed(), n_hash, seeds.data()));
   if (n <= 0 || k <= 0 || n_hash <= 0) {
-    check(da_similarity_mh(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), nullptr));
+    check(da_similarity_mh(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), nullptr));   // always an error here
   }
   NumericMatrix out(n, n);  // column-major; the result is symmetric, so layout does not matter
-  check(da_similarity_mh(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), REAL(out)));
+  const DeviceOpts dev;
+  check(da_similarity_mh_opts(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), REAL(out), dev.get()));
   set_dimnames(out);
   return out;
 }
@@ -106,8 +170,9 @@ NumericMatrix similarityNW(CharacterVector sequences, std::string matrixName = "
   const Packed in(sequences);
   const int64_t n = sequences.length();
   NumericMatrix out(n, n);
-  check(da_similarity_nw(in.residues.data(), in.offsets.data(), n, matrixName.c_str(), gapOpen, gapExt,
-                         n > 0 ? REAL(out) : nullptr));
+  const DeviceOpts dev;
+  check(da_similarity_nw_opts(in.residues.data(), in.offsets.data(), n, matrixName.c_str(), gapOpen, gapExt,
+                              n > 0 ? REAL(out) : nullptr, dev.get()));
   set_dimnames(out);
   return out;
 }
@@ -127,12 +192,12 @@ List similarityMH_edges(CharacterVector sequences, int k = 4, int n_hash = 50, d
   if (n_hash > 0) check(da_hash_family_seeds(hash_seed(), n_hash, seeds.data()));
   double thr = 0;
   int64_t m = 0;
-  check(da_similarity_mh_edges(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), thresh_p, &thr, &m, 0,
-                               nullptr, nullptr, nullptr));
+  da_edges *h = nullptr;                  // one pass: the pipeline runs once, the edges wait in the handle
+  check(da_similarity_mh_edges_begin(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), thresh_p, &h, &thr, &m));
+  const EdgesHandle guard(h);             // released even if the allocations below throw
   IntegerVector from(m), to(m);
   NumericVector weight(m);
-  check(da_similarity_mh_edges(in.residues.data(), in.offsets.data(), n, k, n_hash, seeds.data(), thresh_p, &thr, &m, m,
-                               INTEGER(from), INTEGER(to), REAL(weight)));
+  check(da_edges_fetch(h, m, INTEGER(from), INTEGER(to), REAL(weight)));
   for (int64_t e = 0; e < m; ++e) { from[e] += 1; to[e] += 1; }   // R is 1-based
   return List::create(_["threshold"] = thr,
                       _["edges"] = DataFrame::create(_["from"] = from, _["to"] = to, _["weight"] = weight));
@@ -149,12 +214,13 @@ List similarityNW_edges(CharacterVector sequences, std::string matrixName = "BLO
   const int64_t n = sequences.length();
   double thr = 0;
   int64_t m = 0;
-  check(da_similarity_nw_edges(in.residues.data(), in.offsets.data(), n, matrixName.c_str(), gapOpen, gapExt, thresh_p,
-                               &thr, &m, 0, nullptr, nullptr, nullptr));
+  da_edges *h = nullptr;
+  check(da_similarity_nw_edges_begin(in.residues.data(), in.offsets.data(), n, matrixName.c_str(), gapOpen, gapExt, thresh_p,
+                                     &h, &thr, &m));
+  const EdgesHandle guard(h);
   IntegerVector from(m), to(m);
   NumericVector weight(m);
-  check(da_similarity_nw_edges(in.residues.data(), in.offsets.data(), n, matrixName.c_str(), gapOpen, gapExt, thresh_p,
-                               &thr, &m, m, INTEGER(from), INTEGER(to), REAL(weight)));
+  check(da_edges_fetch(h, m, INTEGER(from), INTEGER(to), REAL(weight)));
   for (int64_t e = 0; e < m; ++e) { from[e] += 1; to[e] += 1; }   // R is 1-based
   return List::create(_["threshold"] = thr,
                       _["edges"] = DataFrame::create(_["from"] = from, _["to"] = to, _["weight"] = weight));

@@ -151,3 +151,41 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"oracle_lib|liborc|dynaalign_oracle|orc_", txt), os.path.join(dirpath, f)
+
+
+def test_opts_struct_layout_and_rccl_binding(lib):
+    """struct da_opts of the header == the ctypes mirror; RCCL can be bound in this image (dlopen of librccl.so.1);
+    validation happens before any device work and keeps the reference's order"""
+    from dynaalign_amd import _capi
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "dynaalign.h"
+    int main(void) { printf("%zu %zu %zu %zu %zu %d %d %d %d\n", sizeof(da_opts), offsetof(da_opts, n_devices), offsetof(da_opts, devices),
+                            offsetof(da_opts, exchange), offsetof(da_opts, phase_ms), DA_EXCHANGE_ROWS, DA_EXCHANGE_ALLGATHER,
+                            DA_EXCHANGE_PEERCOPY, DA_PHASE_COUNT); return 0; }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.dirname(_capi.HEADER_PATH), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        got = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
+    D = _capi.DaOpts
+    assert got == [C.sizeof(D), D.n_devices.offset, D.devices.offset, D.exchange.offset, D.phase_ms.offset,
+                   _capi.DA_EXCHANGE["rows"], _capi.DA_EXCHANGE["allgather"], _capi.DA_EXCHANGE["peercopy"], len(_capi.DA_PHASES)]
+    assert lib.da_rccl_available() == 1
+    import dynaalign_amd as da
+    for kw in ({}, {"devices": [0]}, {"devices": [0, 0], "exchange": "peercopy"}):
+        with pytest.raises(da.DynaAlignError) as e:                      # reference order: empty -> k -> n_hash (src/minHash.cpp:121-131)
+            da.similarityMH([], 0, 0, **kw)
+        assert e.value.code == 1
+        with pytest.raises(da.DynaAlignError) as e:
+            da.similarityMH(["ACDEF"], 0, 0, **kw)
+        assert e.value.code == 2
+        with pytest.raises(da.DynaAlignError) as e:
+            da.similarityNW(["ACDEF"], "PAM250", **kw)
+        assert str(e.value) == "Invalid substitution matrix name: PAM250"
+        with pytest.raises(da.DynaAlignError) as e:
+            da.similarityNW(["AJ", "AA"], **kw)
+        assert str(e.value) == "Invalid amino acid in sequence2: J"
+    with pytest.raises(ValueError):
+        da.similarityMH(["ACDEF"], 4, 50, devices=[0], exchange="ring")
