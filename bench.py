@@ -4,17 +4,22 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full pass of similarityMH(k=4, n_hash=500) over the workload with the
-packed residues already resident in HBM: signature build (K1) + all-pairs compare (K2)
-producing the dense float64 N x N matrix in HBM (what the reference returns to R).  With
-N > 1 ranks the pair space is row-sharded (cyclic tile rows), each rank's compact block is
-exchanged with ONE RCCL all-gather and mirrored/widened to the full float64 matrix on every
-rank; total work is fixed, so `scaling` is "strong".
+A "step" is one full pass of similarityMH(k=4, n_hash=500) over the workload with the packed residues already
+resident in HBM: signature build (K1) + exact re-coding (K1b) + all-pairs compare (K2) producing the dense float64
+N x N matrix in HBM (what the reference returns to R).  `value` is on that boundary -- T_k of SURVEY 8(d): kernels
+only, inputs and result resident in HBM.  With N > 1 ranks the pair space is row-sharded (cyclic tile rows), each
+rank's compact block is exchanged with ONE RCCL all-gather and mirrored / widened to the full float64 matrix on every
+rank (T_g); total work is fixed, so `scaling` is "strong".
 
-Headline workload (BASELINE.json configs[3], the one the metric is quoted on):
-100 000 h3n2-like 20-mers, MinHash k=4 n_hash=500, hash seed 12345.  The same JSON line also
-carries the NW BLOSUM62 figure (`nw`), the dominant kernel's roofline position (`roofline`)
-and the CPU oracle timed on this box's host cores (`cpu_baseline`, rank 0, N=1 only).
+Headline workload (BASELINE.json configs[3], the one the metric is quoted on): 100 000 h3n2-like 20-mers, MinHash
+k=4 n_hash=500, hash seed 12345.  The same JSON line also carries
+    roofline      the dominant kernel (K2): algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak, + the VALU bound
+    nw            similarityNW BLOSUM62/10/4 on the same set (second half of the metric) with its own roofline object
+    uniform       the other SURVEY 8(d) workload, S100k uniform (needs 16 code planes instead of 12)
+    t_h           the host-pointer boundary (what R sees): da_similarity_mh / _nw into a pageable host matrix, PCIe-inclusive
+    edges         similarityMH + clusterbreak's quantile threshold as an edge list
+    clusterbreak  BASELINE configs[4]: clusterbreak(size_max=800, thresh_p=.8) end to end on the device edge path
+    cpu_baseline  the CPU oracle timed on this box's host cores (rank 0, N=1 only) and speedups on the T_h boundary
 """
 import argparse
 import json
@@ -29,6 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BITOP3_PEAK = 62.0e12       # lane-v_bitop3/s this chip sustains in isolation (tools/ubench/inst_rate, profiles/)
+VALU_PEAK = 256 * 4 * 32 * 2.4e9   # lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md chip table)
 
 
 def parse():
@@ -41,6 +47,9 @@ def parse():
     ap.add_argument("--no-nw", action="store_true", help="skip the similarityNW measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-edges", action="store_true", help="skip the threshold + edge-list measurement")
+    ap.add_argument("--no-uniform", action="store_true", help="skip the uniform-peptide leg")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (T_h, PCIe-inclusive) measurement")
+    ap.add_argument("--no-clusterbreak", action="store_true", help="skip the clusterbreak end-to-end run (BASELINE config 5)")
     ap.add_argument("--plane-bits", type=int, default=0, choices=[0, 12, 16, 32],
                     help="0: compare the signatures' exact dictionary codes with as few bit planes as the data needs "
                          "(default); 12 / 16: at least that many code planes; 32: raw signature bits")
@@ -104,16 +113,16 @@ def cpu_baseline(gen, target_s):
     return {
         "value": mh["pairs"] / mh["dt"], "unit": "pairs/s", "cores": mh["threads"], "kind": "port",
         "sample": "CPU oracle (C restatement: reference loop nest + its 2 OpenMP sites) similarityMH k=4 n_hash=500 on the "
-                  "first %d peptides of the same generator: %.1f s" % (ns, mh["dt"]),
+                  "first %d peptides of the same generator, whole call incl. the f64 matrix fill: %.1f s" % (ns, mh["dt"]),
         "nw": {"value": nw["pairs"] / nw["dt"], "unit": "pairs/s", "cores": 1,
                "sample": "CPU oracle similarityNW BLOSUM62/10/4, %d rows x 4000 peptides, 1 thread (the reference's NW loop "
                          "is serial): %.1f s" % (min(rows, 4000), nw["dt"])},
     }
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc*.json):
-    WRITE_SIZE + 2 x FETCH_SIZE KiB (the gfx950 FETCH_SIZE half-count correction of MI355X_MICROARCH.md)."""
+def pmc_kernel(kernel, n):
+    """per-launch counter averages of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*pmc*.json)
+    taken at the same N, + the file they come from"""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -123,32 +132,38 @@ def pmc_traffic(kernel):
             except Exception:
                 continue
             k = d.get("kernels", {}).get(kernel)
-            if k and "WRITE_SIZE" in k and "FETCH_SIZE" in k:
-                best = {"bytes": (k["WRITE_SIZE"] + 2.0 * k["FETCH_SIZE"]) * 1024.0, "source": "profiles/" + f,
-                        "n": d.get("n")}
+            if k and d.get("n") == n:
+                best = dict(k, source="profiles/" + f)
     return best
+
+
+def pmc_traffic(kernel, n):
+    """HBM bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE KiB (the gfx950 FETCH_SIZE half-count correction of
+    MI355X_MICROARCH.md)"""
+    k = pmc_kernel(kernel, n)
+    if k and "WRITE_SIZE" in k and "FETCH_SIZE" in k:
+        return {"bytes": (k["WRITE_SIZE"] + 2.0 * k["FETCH_SIZE"]) * 1024.0, "source": k["source"]}
+    return None
 
 
 def main():
     a = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
+    import __graft_entry__ as g
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if local_rank == 0:
+        g.build()                       # a no-op when the in-tree .so files are current; before anything touches the GPU
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import __graft_entry__ as g
-    if rank == 0:
-        g.build()
-    if world > 1:
         dist.barrier()
     import dynaalign_amd as da
     from dynaalign_amd import _capi, device, sharding, synth
@@ -164,16 +179,17 @@ def main():
     pwork = torch.empty(device.planes_workspace_bytes(n, n_hash), dtype=torch.uint8, device="cuda")
     state = {"bits": 32}
 
-    def signatures_and_planes(e=None):
+    def signatures_and_planes(e=None, seqs=ds, min_bits=a.plane_bits):
         """K1 (signatures) + K1b (exact dictionary codes -> 8 / 12 / 16 bit planes per 32 hash functions);
         --plane-bits 32 keeps the raw signature bits, 12 / 16 set a lower bound on the code planes."""
-        device.minhash_signatures(ds, k, n_hash, d_seeds, out=sig, want_planes=False)
+        device.minhash_signatures(seqs, k, n_hash, d_seeds, out=sig, want_planes=False)
         if e is not None:
             e.record()
-        pl = device.mh_planes(sig, n, n_hash, planes, pwork, a.plane_bits)
+        pl = device.mh_planes(sig, n, n_hash, planes, pwork, min_bits)
         state["bits"] = pl.bits
         return pl
     out = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    cnt16 = None
 
     pairs_mh = n * (n - 1) // 2            # unordered pairs, diagonal excluded (src/minHash.cpp:164)
     pairs_nw = n * (n + 1) // 2            # the reference computes the NW diagonal (src/pairwiseSeqAlign.cpp:342)
@@ -181,10 +197,10 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
     if world == 1:
-        def step():
+        def step(seqs=ds):
             e = [ev() for _ in range(4)]
             e[0].record()
-            pl = signatures_and_planes(e[1])
+            pl = signatures_and_planes(e[1], seqs)
             e[2].record()
             device.mh_compare(pl, n, n_hash, 0, n, True, _capi.DA_OUT_F64, out=out)
             e[3].record()
@@ -194,10 +210,10 @@ def main():
         plan = sharding.Plan(n, rank, world, sharding.MH_TILE)
         work = sharding.PackedWorkspace(plan, n_hash, "cuda")   # counts travel in bits(n_hash) = 9 bits, not 16
 
-        def step():
+        def step(seqs=ds):
             e = [ev() for _ in range(6)]
             e[0].record()
-            pl = signatures_and_planes(e[1])                      # every rank: all signatures (2 MB in)
+            pl = signatures_and_planes(e[1], seqs)                # every rank: all signatures (2 MB in)
             e[2].record()
             sharding.mh_local_block(plan, work, pl, n_hash)
             sharding.pack_local_block(plan, work)
@@ -214,62 +230,74 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    evs = [step() for _ in range(a.steps)]
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def timed_steps(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        evs = [fn() for _ in range(steps)]
+        sync()
+        return max_over_ranks(time.perf_counter() - t0), evs
+
+    dt, evs = timed_steps(step, a.steps, a.warmup)
     phases = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i, nm in enumerate(phase_names)}
     ms_per_step = dt / a.steps * 1e3
     value = pairs_mh / (dt / a.steps)
 
-    # ---- roofline of the dominant kernel (K2 compare); duration from HIP events on the launch stream
-    k2_key = "k2_compare" if world == 1 else "k2_compare_shard"
-    k2 = phases[k2_key] * 1e-3
-    plane_bits = state["bits"]
-    planes_row_bytes = 2 * 16 * plane_bits * 4        # two copies x 16 groups x planes x 4 B
-    T = (n + 127) // 128
-    if world == 1:
-        bytes_k2 = n * planes_row_bytes + n * n * 8   # read the bit planes once + write the f64 N x N
-        tiles = T * (T + 1) // 2
-    else:
-        tiles = sum(T - t for t in range(rank, T, world))
-        bytes_k2 = n * planes_row_bytes + tiles * 128 * 128 * 2   # this rank's uint16 tiles
-    lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
-    # 12 code planes, symmetric mode: the hand-scheduled kernel does all but the diagonal / border tiles
-    k2_name = "k_mh_compare_a12<true>" if (world == 1 and plane_bits == 12) else "k_mh_compare<true, true, %d>" % plane_bits
-    traffic = pmc_traffic(k2_name) if world == 1 else None
-    roof = {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,
-            "traffic": traffic["bytes"] if traffic and traffic.get("n") == n else None,
-            "traffic_source": traffic["source"] if traffic and traffic.get("n") == n else None,
-            "avg_launch_ms": k2 * 1e3, "algorithmic_bytes_per_launch": bytes_k2, "plane_bits": plane_bits,
-            "valu": {"note": "the unit that actually binds: bit-sliced compare = 1 v_bitop3 per pair per bit plane; "
-                             "peak = isolated v_bitop3 issue rate measured on this chip",
-                     "lane_ops_per_launch": lane_ops, "achieved_lane_ops_per_s": lane_ops / k2,
-                     "peak_lane_ops_per_s": BITOP3_PEAK, "frac": lane_ops / k2 / BITOP3_PEAK}}
+    def k2_roofline(k2_ms, plane_bits, wl_n=n):
+        """roofline object of the compare kernel: algorithmic bytes (with the plane words actually read) /
+        HIP-event duration, against the 8 TB/s HBM peak; + the VALU bound that actually binds"""
+        k2 = k2_ms * 1e-3
+        planes_row_bytes = 2 * 16 * plane_bits * 4        # two copies x 16 groups x planes x 4 B
+        T = (wl_n + 127) // 128
+        if world == 1:
+            bytes_k2 = wl_n * planes_row_bytes + wl_n * wl_n * 8   # read the bit planes once + write the f64 N x N
+            tiles = T * (T + 1) // 2
+        else:
+            tiles = sum(T - t for t in range(rank, T, world))
+            bytes_k2 = wl_n * planes_row_bytes + tiles * 128 * 128 * 2   # this rank's uint16 tiles
+        lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
+        # 12 code planes, symmetric mode: the hand-scheduled kernel does all but the diagonal / border tiles
+        k2_name = "k_mh_compare_a12<true>" if (world == 1 and plane_bits == 12) else "k_mh_compare<true, true, %d>" % plane_bits
+        traffic = pmc_traffic(k2_name, wl_n) if world == 1 else None
+        return {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                "avg_launch_ms": k2 * 1e3, "algorithmic_bytes_per_launch": bytes_k2, "plane_bits": plane_bits,
+                "valu": {"note": "the unit that actually binds: bit-sliced compare = 1 v_bitop3 per pair per bit plane; "
+                                 "peak = isolated v_bitop3 issue rate measured on this chip",
+                         "lane_ops_per_launch": lane_ops, "achieved_lane_ops_per_s": lane_ops / k2,
+                         "peak_lane_ops_per_s": BITOP3_PEAK, "frac": lane_ops / k2 / BITOP3_PEAK}}
 
+    k2_key = "k2_compare" if world == 1 else "k2_compare_shard"
     line = {
         "metric": "sequence-pairs/sec (MinHash k=4 n_hash=500; NW BLOSUM62) at 1/2/4/8 MI355X",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
+        "boundary": "T_k: kernels only, packed residues and the dense f64 result resident in HBM" if world == 1 else
+                    "T_g: kernels + one RCCL all-gather + finalize, dense f64 result resident in every rank's HBM",
         "config": {"workload": "similarityMH k=4 n_hash=500 on %d %s 20-mers (hash seed 12345), dense f64 NxN in HBM"
                                % (n, "h3n2-like" if a.workload == "h3n2like" else "uniform"),
                    "n": n, "k": k, "n_hash": n_hash, "pairs": pairs_mh,
                    "sharding": "1 GPU: upper-triangle tiles + mirrored store" if world == 1
                    else "cyclic tile rows over %d ranks, one RCCL all-gather of the 9-bit packed counts, mirror+widen on every rank" % world},
-        "roofline": roof,
+        "roofline": k2_roofline(phases[k2_key], state["bits"]),
         "phases_ms": phases,
     }
+    if world > 1:
+        line["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                        "all_gather_bytes_per_rank": int(work.block_bytes), "all_gather_ms": phases["all_gather"],
+                        "finalize_ms": phases["finalize"]}
 
-    # ---- similarityNW on the same set (second half of the metric); one timed launch
+    # ---- similarityNW on the same set (second half of the metric), >= 3 timed launches
     if not a.no_nw:
         bad = device.nw_encode(ds)
         assert int(bad.item()) == 0
@@ -279,22 +307,34 @@ def main():
             nplan = sharding.Plan(n, rank, world, sharding.NW_TILE)
             nwork = sharding.Workspace(nplan, "cuda")
             run_nw = lambda: sharding.nw_sharded_step(nplan, nwork, ds, out)
-        run_nw()
-        sync()
-        t0 = time.perf_counter()
-        run_nw()
-        sync()
-        t_nw = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([t_nw], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_nw = float(t.item())
+        nw_launches = 3
+        t_nw, _ = timed_steps(run_nw, nw_launches, 1)
+        t_nw /= nw_launches
         cells = pairs_nw * L * L
-        line["nw"] = {"workload": "similarityNW BLOSUM62 go=10 ge=4, same %d 20-mers, dense f64 NxN in HBM" % n,
-                      "value": pairs_nw / t_nw, "unit": "pairs/s", "ms": t_nw * 1e3, "gcups": cells / t_nw / 1e9,
-                      "hbm_GBs": (n * L + n * n * 8) / t_nw / 1e9, "hbm_frac": (n * L + n * n * 8) / t_nw / 1e9 / HBM_PEAK_GBS}
+        nw_obj = {"workload": "similarityNW BLOSUM62 go=10 ge=4, same %d 20-mers, dense f64 NxN in HBM" % n,
+                  "value": pairs_nw / t_nw, "unit": "pairs/s", "ms": t_nw * 1e3, "launches_timed": nw_launches,
+                  "gcups": cells / t_nw / 1e9}
+        if world == 1:
+            nw_kernel = "k_nw_short<20, true>"
+            pm = pmc_kernel(nw_kernel, n)
+            bytes_nw = n * L + n * n * 8
+            roof = {"kernel": nw_kernel, "bound": "valu", "hbm": {"achieved": bytes_nw / t_nw / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                    "frac": bytes_nw / t_nw / 1e9 / HBM_PEAK_GBS,
+                                                                    "algorithmic_bytes_per_launch": bytes_nw},
+                    "peak": VALU_PEAK, "unit": "lane-ops/s",
+                    "peak_note": "256 CU x 4 SIMD x 32 lanes x 2.4 GHz; the kernel is integer-VALU-bound by construction (no MFMA: a DP recurrence is not a contraction)"}
+            if pm and "SQ_INSTS_VALU" in pm:
+                lane_ops = pm["SQ_INSTS_VALU"] * 64.0                       # wave instructions x 64 lanes
+                roof.update({"lane_ops_per_launch": lane_ops, "valu_insts_per_cell": pm["SQ_INSTS_VALU"] * 64.0 / (cells if cells else 1) ,
+                             "achieved": lane_ops / t_nw, "frac": lane_ops / t_nw / VALU_PEAK, "counter_source": pm["source"]})
+                if "GRBM_GUI_ACTIVE" in pm:                                  # sum over the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+                    clk = pm["GRBM_GUI_ACTIVE"] / 8.0 / t_nw
+                    roof.update({"effective_clock_hz": clk, "peak_at_effective_clock": VALU_PEAK * clk / 2.4e9,
+                                 "frac_at_effective_clock": lane_ops / t_nw / (VALU_PEAK * clk / 2.4e9)})
+            nw_obj["roofline"] = roof
+        line["nw"] = nw_obj
 
-    # ---- similarityMH + clusterbreak's quantile threshold as a distributed edge list:
+    # ---- similarityMH + clusterbreak's quantile threshold as an edge list:
     # shard compare -> histogram -> ONE all-reduce of n_hash+1 words -> exact type-7 quantile -> local edges.
     # No N x N exchange, so this is the variant of the path whose whole-job time scales with the rank count.
     if not a.no_edges:
@@ -322,12 +362,9 @@ def main():
         t0 = time.perf_counter()
         thr, ei, ej, evv, cnt = run_edges()
         sync()
-        t_e = time.perf_counter() - t0
+        t_e = max_over_ranks(time.perf_counter() - t0)
         tot = cnt.clone()
         if world > 1:
-            t = torch.tensor([t_e], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_e = float(t.item())
             dist.all_reduce(tot)
         line["edges"] = {"workload": "similarityMH k=4 n_hash=500 + quantile(S[upper.tri(S)], 0.8) threshold -> edge list "
                                      "(R/clusterbreak.R:219-221), same %d peptides; %s" % (n, "one GPU: symmetric uint16 compare -> histogram -> "
@@ -336,13 +373,90 @@ def main():
                          "edges_total": int(tot.item()), "edge_list_bytes": int(tot.item()) * 10}
         del ei, ej, evv
 
+    # ---- the other SURVEY 8(d) workload: S100k uniform.  Its column dictionaries are larger (D ~ 15 000 -> 16 code planes)
+    if world == 1 and not a.no_uniform and a.workload == "h3n2like":
+        ures, uoff = synth.uniform_peptides(n, L)
+        uds = device.DeviceSequences(ures, uoff, "cuda")
+        usteps = max(2, min(a.steps, 3))
+        udt, uevs = timed_steps(lambda: step(uds), usteps, 1)
+        uph = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in uevs])) for i, nm in enumerate(phase_names)}
+        line["uniform"] = {"workload": "similarityMH k=4 n_hash=500 on %d uniform 20-mers (SURVEY 8(d) S100k), dense f64 NxN in HBM" % n,
+                           "value": pairs_mh / (udt / usteps), "unit": "pairs/s", "ms_per_step": udt / usteps * 1e3, "steps": usteps,
+                           "plane_bits": state["bits"], "phases_ms": uph, "roofline": k2_roofline(uph["k2_compare"], state["bits"])}
+        del uds
+        signatures_and_planes()                       # back to the headline set (sig / planes are shared buffers)
+
+    # ---- BASELINE configs[4]: clusterbreak(size_max=800, thresh_p=.8) end to end, GPU similarityMH backend on the
+    # device edge path (signatures resident; per recursion level codes + compare + histogram + quantile + edges), host Louvain
+    if world == 1 and not a.no_clusterbreak:
+        from dynaalign_amd.session import MinHashSession
+        out = cnt16 = None                  # the 80 GB result buffer is not needed any more (closures above are done)
+        torch.cuda.empty_cache()
+        seqs = synth.to_strings(res, off)
+        t0 = time.perf_counter()
+        sess = MinHashSession(seqs, k, n_hash, seed=12345)
+        torch.cuda.synchronize()
+        t_sess = time.perf_counter() - t0
+        r = da.clusterbreak(seqs, thresh_p=0.8, size_max=800, size_min=3, session=sess, cluster_seed=1)
+        t_cb = time.perf_counter() - t0
+        sizes = np.unique(r["clustered_seq"][:, 1], return_counts=True)[1] if len(r["clustered_seq"]) else np.zeros(1, int)
+        line["clusterbreak"] = {
+            "workload": "clusterbreak(size_max=800, thresh_p=.8, size_min=3) on the same %d peptides, sim = similarityMH(k=4, n_hash=500) "
+                        "through MinHashSession.edges (device edge path), cluster_fn = da_louvain(resolution 1.05)" % n,
+            "wall_s": t_cb, "session_setup_s": t_sess, "calls": r.calls, "convergence": r.convergence,
+            "similarity_s": float(sum(l["similarity_s"] for l in r.levels)), "louvain_s": float(sum(l["cluster_s"] for l in r.levels)),
+            "edges_first_level": r.levels[0]["edges"], "threshold_first_level": r.levels[0]["threshold"],
+            "clusters": int(len(sizes)), "largest_cluster": int(sizes.max()), "clustered": int(len(r["clustered_seq"])),
+            "filtered": int(len(r["filtered_seq"])),
+            "parity": "memberships identical to the oracle dense path at N = 12 000 (tests/test_gpu_clusterbreak.py); at this N the dense path "
+                      "needs an 80 GB matrix per level and is not run"}
+        del sess, r
+        torch.cuda.empty_cache()
+
+    # ---- T_h: the host-pointer boundary (what R sees): da_similarity_mh / da_similarity_nw into a pageable host matrix,
+    # upload + kernels + pipelined D2H.  PCIe-bound; never `value`.
+    if world == 1 and not a.no_host:
+        import psutil
+        out = cnt16 = None
+        torch.cuda.empty_cache()
+        avail = psutil.virtual_memory().available
+        nh = n
+        while nh > 2000 and nh * nh * 8 * 1.5 + (8 << 30) > avail:
+            nh = nh // 2
+        hres, hoff = getattr(synth, gen_name)(nh, L)
+        hout = np.empty((nh, nh), np.float64)
+        lib = _capi.load()
+        th = {"n": nh, "workload": "host-pointer entry points (the R glue's calls) on the first-generated %d peptides: upload + kernels + D2H "
+                                   "into a pageable host f64 matrix (PCIe-inclusive)" % nh, "matrix_bytes": nh * nh * 8}
+        t0 = time.perf_counter()
+        _capi.check(lib.da_similarity_mh(hres.ctypes.data, hoff.ctypes.data, nh, k, n_hash, seeds.ctypes.data, hout.ctypes.data))
+        t_first = time.perf_counter() - t0                                   # includes the first touch of the destination pages
+        t0 = time.perf_counter()
+        _capi.check(lib.da_similarity_mh(hres.ctypes.data, hoff.ctypes.data, nh, k, n_hash, seeds.ctypes.data, hout.ctypes.data))
+        t_mh = time.perf_counter() - t0
+        th["mh"] = {"s": t_mh, "s_first_call_cold_pages": t_first, "value": nh * (nh - 1) // 2 / t_mh, "unit": "pairs/s",
+                    "effective_GBs": nh * nh * 8 / t_mh / 1e9}
+        if not a.no_nw:
+            t0 = time.perf_counter()
+            _capi.check(lib.da_similarity_nw(hres.ctypes.data, hoff.ctypes.data, nh, b"BLOSUM62", 10, 4, hout.ctypes.data))
+            t_nwh = time.perf_counter() - t0
+            th["nw"] = {"s": t_nwh, "value": nh * (nh + 1) // 2 / t_nwh, "unit": "pairs/s", "effective_GBs": nh * nh * 8 / t_nwh / 1e9}
+        line["t_h"] = th
+        del hout
+
     # ---- CPU oracle on this box's host cores (baseline only; rank 0, N = 1)
     if rank == 0 and world == 1 and not a.no_cpu:
         cb = cpu_baseline(gen_name, a.cpu_seconds)
         line["cpu_baseline"] = cb
-        line["speedup_vs_cpu"] = {"mh": value / cb["value"]}
+        sp = {"boundary": "T_h (whole call, result in host memory) on both sides where t_h was measured, else T_k / whole-call CPU"}
+        mh_gpu = line.get("t_h", {}).get("mh", {}).get("value")
+        nw_gpu = line.get("t_h", {}).get("nw", {}).get("value")
+        sp["mh"] = (mh_gpu or value) / cb["value"]
+        sp["mh_kernels_only"] = value / cb["value"]
         if "nw" in line:
-            line["speedup_vs_cpu"]["nw"] = line["nw"]["value"] / cb["nw"]["value"]
+            sp["nw"] = (nw_gpu or line["nw"]["value"]) / cb["nw"]["value"]
+            sp["nw_kernels_only"] = line["nw"]["value"] / cb["nw"]["value"]
+        line["speedup_vs_cpu"] = sp
 
     if rank == 0:
         print(json.dumps(line))
