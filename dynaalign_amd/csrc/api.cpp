@@ -4,6 +4,7 @@
 // order and message texts, packing, H2D/D2H, and kernel launches.  There is
 // deliberately NO CPU implementation of the hot path in this library.
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <condition_variable>
@@ -209,6 +210,22 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
   cleanup();
   return rc;
 }
+
+// DYNAALIGN_TRACE=1: wall-clock checkpoints of the host-pointer paths on stderr (where does T_h go?)
+struct Trace {
+  const bool on = getenv("DYNAALIGN_TRACE") != nullptr;
+  const char *what;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  explicit Trace(const char *w) : what(w) {}
+  void mark(const char *step) {
+    if (!on) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[dynaalign] %s: %-28s %9.3f ms (total %9.3f ms)\n", what, step,
+            std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
+    last = now;
+  }
+};
 
 // How many result rows to keep on the device at once (host-pointer paths).
 int64_t rows_per_block(int64_t n, size_t bytes_per_elem) {
@@ -830,12 +847,14 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
   int64_t total, max_len;
   if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
   if ((rc = require_device()) != DA_OK) return rc;
+  Trace tr("similarityMH host path");
   DeviceInput in;
   if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
   const int64_t lds = sig_ld_for(n_hash);
   DevBuf sig, planes;
   if ((rc = sig.alloc((size_t)n * lds * sizeof(uint32_t))) != DA_OK) return rc;
   if ((rc = planes.alloc((size_t)mh_planes_words(n, n_hash) * sizeof(uint32_t))) != DA_OK) return rc;
+  tr.mark("upload + small allocations");
   rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, n_hash,
                                  in.seeds.as<uint32_t>(), sig.as<uint32_t>(), lds, nullptr);
   if (rc != DA_OK) return rc;
@@ -848,16 +867,20 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
       return rc;
     DA_HIP_TRY(hipStreamSynchronize(nullptr));   // the workspace is released here
   }
+  tr.mark("signatures + codes");
   const size_t esz = kind == DA_OUT_F64 ? sizeof(double) : sizeof(uint16_t);
   const int64_t rows_total = row_end - row_begin;
   const int64_t blk = rows_per_block(n, esz);
   const bool whole = (row_begin == 0 && row_end == n && blk >= n);
   DevBuf dout;
   if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * esz)) != DA_OK) return rc;
+  tr.mark(whole ? "result allocation (whole)" : "result allocation (row blocks)");
   if (whole) {  // everything fits: compare only the upper triangle, store both halves
     rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, kind, dout.p, n, nullptr, bits);
     if (rc != DA_OK) return rc;
+    tr.mark("compare");
     if ((rc = d2h_pipelined(out, dout.p, (size_t)n * (size_t)n * esz)) != DA_OK) return rc;
+    tr.mark("device -> host");
     return DA_OK;
   }
   for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {

@@ -275,6 +275,12 @@ __device__ __forceinline__ bool a12_takes(int ti, int tj, int64_t n, int64_t ld,
 // 4 waves per SIMD.  The C++ around it decodes the tile, hands five per-lane values over in v120..v124, reads the
 // 32 packed mismatch counters back from LDS and stores the tile like k_mh_compare's straight-line epilogue.
 // Symmetric mode, interior off-diagonal tiles only (a12_takes).
+#ifndef K2_LOOP_INC
+#define K2_LOOP_INC "k2_loop_p12.inc"
+#endif
+#ifndef K2_PRO_PRIO
+#define K2_PRO_PRIO 0     // wave priority of the tile prologue (decode + address arithmetic before the stage loop)
+#endif
 constexpr int K2_A12_TABLE_MAX = 3 * 2 * K2_TILE * 3 * 16 / 8;   // doubles that fit the 12-plane kernel's ring (3 stages x 256 rows x 48 B)
 template <bool F64>
 __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
@@ -283,12 +289,16 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   constexpr int PL = 12, SEGS = 3, STAGE_UNITS = 2 * K2_TILE * SEGS;
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring; afterwards counters, then the ratio table
   static_assert(sizeof(lds_ab) / (sizeof(double)) == K2_A12_TABLE_MAX, "launch_mh_compare's table guard must match the ring size");
+  if (K2_PRO_PRIO) __builtin_amdgcn_s_setprio(K2_PRO_PRIO);
+  K2_STAMP(0);
+  K2_STAMP_HW();
   const int64_t bid = blockIdx.x;
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
   const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
   if (L >= ntiles) return;
   const TileId tl = decode_tile(L, T, T, true);
   if (!tl.valid || !a12_takes(tl.ti, tl.tj, n, ld, out_v, F64)) return;
+  if (!F64) K2_STAMP(6);                                      // (timing build, uint16 kind: prologue split)
   const int64_t I0 = (int64_t)tl.ti * K2_TILE, J0 = (int64_t)tl.tj * K2_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tx = ((wave & 1) << 3) + (lane & 7), ty = ((wave >> 1) << 3) + (lane >> 3);
@@ -298,6 +308,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   const int u = wave * SEGS * 64 + lane, sl0 = u / SEGS, sl = sl0 & 127;
   const uint32_t *src = planes + (sl0 < 128 ? 0 : pg.copy_words) +
                         plane_unit_word(pg, (sl0 < 128 ? I0 : J0) + k2_row_of_slot(sl), 0, u - sl0 * SEGS);
+  if (!F64) K2_STAMP(7);
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)lds_ab);
   const uint32_t a_off = lds_base + (uint32_t)(ty * SEGS * 16);
   const uint32_t b_off = lds_base + (uint32_t)((K2_TILE * SEGS + tx * SEGS) * 16);
@@ -306,45 +317,67 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = 128u * PL * 4u;
   const uint32_t wave_id = __builtin_amdgcn_readfirstlane((uint32_t)wave);
   const uint32_t src_lo_u = __builtin_amdgcn_readfirstlane(src_lo), src_hi_u = __builtin_amdgcn_readfirstlane(src_hi);   // lane 0's source
+  K2_STAMP(1);
+  // the lane's 32 packed mismatch counters (columns 2j, 2j+1 per register) leave the block in v64..v95
+  uint32_t mis[8][4];
+  uint32_t tid_after;
   {
     register uint32_t r120 asm("v120") = a_off;
     register uint32_t r121 asm("v121") = b_off;
     register uint32_t r122 asm("v122") = src_lo;
     register uint32_t r123 asm("v123") = src_hi;
     register uint32_t r124 asm("v124") = wb;
+#define K2_CNT(i) register uint32_t c##i asm("v" #i);
+    K2_CNT(64) K2_CNT(65) K2_CNT(66) K2_CNT(67) K2_CNT(68) K2_CNT(69) K2_CNT(70) K2_CNT(71) K2_CNT(72) K2_CNT(73) K2_CNT(74)
+    K2_CNT(75) K2_CNT(76) K2_CNT(77) K2_CNT(78) K2_CNT(79) K2_CNT(80) K2_CNT(81) K2_CNT(82) K2_CNT(83) K2_CNT(84) K2_CNT(85)
+    K2_CNT(86) K2_CNT(87) K2_CNT(88) K2_CNT(89) K2_CNT(90) K2_CNT(91) K2_CNT(92) K2_CNT(93) K2_CNT(94) K2_CNT(95)
+#undef K2_CNT
     asm volatile(
-#include "k2_loop_p12.inc"
-        : "+v"(r122), "+v"(r123)                                 // the block reuses them as an operand buffer
+#include K2_LOOP_INC
+        : "+v"(r122), "+v"(r123),                                // the block reuses them as an operand buffer
+          "=v"(c64), "=v"(c65), "=v"(c66), "=v"(c67), "=v"(c68), "=v"(c69), "=v"(c70), "=v"(c71), "=v"(c72), "=v"(c73), "=v"(c74),
+          "=v"(c75), "=v"(c76), "=v"(c77), "=v"(c78), "=v"(c79), "=v"(c80), "=v"(c81), "=v"(c82), "=v"(c83), "=v"(c84), "=v"(c85),
+          "=v"(c86), "=v"(c87), "=v"(c88), "=v"(c89), "=v"(c90), "=v"(c91), "=v"(c92), "=v"(c93), "=v"(c94), "=v"(c95)
         : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_id), [sl] "s"(src_lo_u), [sh] "s"(src_hi_u),
           "v"(r120), "v"(r121), "v"(r124)
         : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",   // m0 is saved in s47 and restored by the block
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
           "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
-          "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
-          "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99",
+          "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",
           "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
           "v117", "v118", "v119");
+    // everything lane-dependent the epilogue needs is re-derived from v124 (4 * thread id), which survives the block:
+    // nothing per-lane has to live across it (the block clobbers all but four VGPRs; hipcc spilled to scratch otherwise)
+    asm volatile("" : "+v"(r124));
+    tid_after = r124 >> 2;
+    const uint32_t cnt[32] = {c64, c65, c66, c67, c68, c69, c70, c71, c72, c73, c74, c75, c76, c77, c78, c79,
+                              c80, c81, c82, c83, c84, c85, c86, c87, c88, c89, c90, c91, c92, c93, c94, c95};
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mis[r][c] = cnt[4 * r + c];
   }
+  K2_STAMP(2);
 #ifdef DA_K2_DEBUG
   if (g_k2_debug && tl.ti == 0 && tl.tj == 1) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(lds_ab);
     for (int i = tid; i < 3 * STAGE_UNITS * 4; i += K2_THREADS) g_k2_debug[i] = w[i];
   }
 #endif
-  // the lane's 32 packed mismatch counters (columns 2j, 2j+1 per register) come back through LDS
-  const uint32_t *wbp = reinterpret_cast<const uint32_t *>(lds_ab) + tid;
-  uint32_t mis[8][4];
-#pragma unroll
-  for (int r = 0; r < 8; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) mis[r][c] = wbp[(4 * r + c) * K2_THREADS];
   const uint32_t nn = (uint32_t)n_hash * 0x10001u;             // two match counts per register (no borrow: each <= n_hash)
+  // lane coordinates again, from the value that crossed the block (same formulas as above)
+  const int tid_e = (int)tid_after, wave_e = tid_e >> 6, lane_e = tid_e & 63;
+  const int tx_e = ((wave_e & 1) << 3) + (lane_e & 7), ty_e = ((wave_e >> 1) << 3) + (lane_e >> 3);
+#define tx tx_e
+#define ty ty_e
   if (F64) {
     double *ratio = reinterpret_cast<double *>(lds_ab);
-    __syncthreads();                                           // everyone has its counters: the area becomes the table
-    for (int c = tid; c <= n_hash; c += K2_THREADS) ratio[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
+    __syncthreads();                                           // everyone has left the ring: the area becomes the table
+    for (int c = tid_e; c <= n_hash; c += K2_THREADS) ratio[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
     __syncthreads();
+    K2_STAMP(6);
+    K2_STAMP(7);
     const char *tb = reinterpret_cast<const char *>(ratio);
     double *out = reinterpret_cast<double *>(out_v);
 #pragma unroll
@@ -387,6 +420,9 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
       }
     }
   }
+  K2_STAMP(3);
+#undef tx
+#undef ty
 }
 
 // PL = bit planes per group of 32 hash functions: 32 (raw uint32 values) or 16 / 12 / 8 (dictionary

@@ -23,6 +23,8 @@ SPREAD = int(os.environ.get("K2ASM_SPREAD", "0"))   # experiment: one DMA instru
 SDWA = int(os.environ.get("K2ASM_SDWA", "0"))       # experiment: add the odd column's popcount into the counter's high half with an SDWA add
 EPRIO = int(os.environ.get("K2ASM_EPRIO", "0"))     # wave priority after the loop (tile epilogue)
 SAFE = int(os.environ.get("K2ASM_SAFE", "0"))   # debugging: 1 = drain after every LDS read and DMA wait
+REGOUT = int(os.environ.get("K2ASM_REGOUT", "1"))   # 1: the 32 packed counters leave the block in v64..v95 (asm outputs);
+# 0: through LDS (barrier + 32 ds_write_b32 + wait, read back by the C++ epilogue -- the first version: +1 us per tile)
 
 SEGS, STEPS = 3, 6           # 12 planes: 3 segments of 16 bytes = 6 steps of 8 bytes
 STAGE_BYTES = 256 * SEGS * 16  # 12288
@@ -224,8 +226,9 @@ count_group()
 # ---- counters -> LDS (plane k of the write-back area = 1 KiB of lane-consecutive dwords), after everyone left the ring
 if PRIO or EPRIO:
     e("s_setprio %d" % EPRIO)
-e("s_barrier")
-if not DUMP:
+if not REGOUT:
+    e("s_barrier")
+if not DUMP and not REGOUT:
     e("v_add_u32 v125, %[lb], v124")
     for r in range(8):
         for c2 in range(4):

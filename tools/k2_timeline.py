@@ -46,7 +46,11 @@ def main():
          "prologue_us": [float(np.mean(pro)), float(np.percentile(pro, 50)), float(np.percentile(pro, 95))],
          "loop_us": [float(np.mean(loop)), float(np.percentile(loop, 50)), float(np.percentile(loop, 95))],
          "epilogue_issue_us": [float(np.mean(epi)), float(np.percentile(epi, 50)), float(np.percentile(epi, 95))]}
-    if (t[:, 6] > 0).all() and (t[:, 7] > 0).all():      # f64 kind: table built / direct stores issued
+    if kind != _capi.DA_OUT_F64 and (t[:, 6] > 0).all() and (t[:, 7] > 0).all():   # uint16 kind, a12 kernel: prologue split
+        r["prologue_parts_us"] = {"entry_to_tile_decoded": float(np.mean((t[:, 6] - t[:, 0]) * tick)),
+                                  "tile_decoded_to_dma_source": float(np.mean((t[:, 7] - t[:, 6]) * tick)),
+                                  "dma_source_to_loop": float(np.mean((t[:, 1] - t[:, 7]) * tick))}
+    elif (t[:, 6] > 0).all() and (t[:, 7] > 0).all():      # f64 kind: table built / direct stores issued
         r["epilogue_parts_us"] = {"ratio_table": float(np.mean((t[:, 6] - t[:, 2]) * tick)),
                                   "direct_stores": float(np.mean((t[:, 7] - t[:, 6]) * tick)),
                                   "mirrored_stores": float(np.mean((t[:, 3] - t[:, 7]) * tick))}
@@ -60,18 +64,27 @@ def main():
     # time-weighted number of workgroups inside the loop, sampled over the kernel
     t0 = t[:, 0].min()
     grid = np.linspace(t0, t[:, 3].max(), 4000)
-    frac = np.zeros(5)
+    frac = np.zeros(6)
     sample_cus = np.unique(cus)[:: max(1, ncu // 32)]
     for c in sample_cus:
         m = ts[cus == c]
         inloop = ((m[:, 1][None, :] <= grid[:, None]) & (grid[:, None] < m[:, 2][None, :])).sum(1)
         resident = ((m[:, 0][None, :] <= grid[:, None]) & (grid[:, None] < m[:, 3][None, :])).sum(1)
-        for k in range(4):
+        for k in range(5):
             frac[k] += np.mean(inloop == k)
-        frac[4] += np.mean(resident)
-    r["time_fraction_with_k_workgroups_in_loop"] = [float(x / len(sample_cus)) for x in frac[:4]]
-    r["mean_resident_workgroups_by_stamps"] = float(frac[4] / len(sample_cus))
+        frac[5] += np.mean(resident)
+    r["time_fraction_with_k_workgroups_in_loop"] = [float(x / len(sample_cus)) for x in frac[:5]]
+    r["mean_resident_workgroups_by_stamps"] = float(frac[5] / len(sample_cus))
     r["tiles_per_cu"] = float(len(t) / ncu)
+    # relaunch gap: on a CU with S resident workgroups, the (k+S)-th start follows the k-th exit (both sorted)
+    gaps = []
+    for c in sample_cus:
+        m = ts[cus == c]
+        S = int(round(r["mean_resident_workgroups_by_stamps"] + 0.49))
+        st, ex = np.sort(m[:, 0]), np.sort(m[:, 3])
+        if len(st) > 2 * S:
+            gaps.append(np.median((st[S:] - ex[:len(st) - S]) * tick))
+    r["relaunch_gap_us_median"] = float(np.median(gaps)) if gaps else None
     print(json.dumps(r))
 
 

@@ -104,7 +104,8 @@ def run(tx=5, ty=11, seed=1, inc=INC):
                     aw=word(s,arow,p); bw=word(s,bcol,p^1)
                     dd|=aw^bw
                 mism+=bin(dd).count('1')
-            got=(wb[4*r+c//2]>>(16*(c&1)))&0xffff
+            packed = wb[4*r+c//2] if wb else V[64+4*r+c//2]      # through LDS, or left in v64..v95 (K2ASM_REGOUT)
+            got=(packed>>(16*(c&1)))&0xffff
             if got!=mism: bad+=1
     return issued, bad
 
