@@ -160,7 +160,11 @@ __device__ __forceinline__ uint32_t or_xor(uint32_t d, uint32_t a, uint32_t b) {
 typedef double da_double2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_store2(double *p, double a, double b) {
   da_double2_t v = {a, b};
+#ifdef K2_PLAIN_STORES   // experiment (tools/k2_variants.sh): write-back stores instead of streaming ones
+  *reinterpret_cast<da_double2_t *>(p) = v;
+#else
   __builtin_nontemporal_store(v, reinterpret_cast<da_double2_t *>(p));
+#endif
 }
 
 #ifndef K2_RING_DEPTH
@@ -365,6 +369,9 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
     for (int i = tid; i < 3 * STAGE_UNITS * 4; i += K2_THREADS) g_k2_debug[i] = w[i];
   }
 #endif
+#ifdef K2_NO_STORES   // experiment: how long does the kernel take without its epilogue (tools/k2_variants.sh)?
+  if (n_hash > 0) { if (mis[0][0] == 0xdeadbeefu) reinterpret_cast<uint32_t *>(out_v)[0] = tid_after; return; }
+#endif
   const uint32_t nn = (uint32_t)n_hash * 0x10001u;             // two match counts per register (no borrow: each <= n_hash)
   // lane coordinates again, from the value that crossed the block (same formulas as above)
   const int tid_e = (int)tid_after, wave_e = tid_e >> 6, lane_e = tid_e & 63;
@@ -423,6 +430,182 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   K2_STAMP(3);
 #undef tx
 #undef ty
+}
+
+// ---- the same 12-plane loop, PERSISTENT: a workgroup walks a sequence of tiles and its DMA ring never drains ----
+// (Opt-in, see launch_mh_compare.)  k_mh_compare_a12 spends 29 % of a workgroup's life outside the plane loop (profiles/r02_b_k2_timeline_*.json: 8.6 us from
+// launch to the loop, 14.5 us of stores, 1.4 us until the slot's next workgroup starts, against 59 us in the loop), so on
+// average only 2.8 of the CU's 4 workgroups feed the VALU.  Here the grid is one workgroup per resident slot (4 per CU);
+// workgroup (XCD x, slot s) takes the tile ids x*per_xcd + s + k*wg_per_xcd, k = 0, 1, ... -- the XCD's workgroups sweep a
+// window of consecutive ids together, so the L2 reuse of the banded order is kept.  The generated block (K2ASM_PERSIST=1,
+// k2_loop_p12p.inc) issues the NEXT tile's first two stages during the last two stages of the current one and waits for them
+// before it ends; the C++ epilogue then issues the tile's stores and the next block starts computing at once -- the stores
+// drain under its first two stages (vmcnt counts loads and stores together and in order: the block's first counted wait is at
+// stage 2).  The count -> double table lives in its own 4 KiB of LDS (built once per workgroup; 36 + 4 KiB x 4 workgroups =
+// the CU's 160 KiB), so the epilogue needs no barrier.  float64 output therefore needs n_hash <= 511; larger n_hash and
+// single-stage inputs (n_hash <= 32) stay with k_mh_compare_a12.
+#ifndef K2_LOOP_INC_P
+#define K2_LOOP_INC_P "k2_loop_p12p.inc"
+#endif
+constexpr int K2_P12_TABLE = 512;
+template <bool F64>
+__global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
+                                                                  void *__restrict__ out_v, int64_t ld, int64_t ntiles,
+                                                                  int64_t per_xcd, int wg_per_xcd) {
+  constexpr int PL = 12, SEGS = 3, STAGE_UNITS = 2 * K2_TILE * SEGS;
+  __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring
+  __shared__ double ratio_tab[F64 ? K2_P12_TABLE : 1];
+  const int T = (int)((n + K2_TILE - 1) / K2_TILE);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  // tile ids fit 31 bits (the launcher checks): 32-bit scalars, so that loop control stays on the scalar unit -- nothing
+  // wave-uniform may end up in a VGPR that has to live across the block (it clobbers the VGPR file; hipcc would spill to
+  // scratch and reload behind a vmcnt wait in the middle of the tile's stores)
+  const int lim = (int)(((int64_t)(xcd + 1) * per_xcd < ntiles) ? (int64_t)(xcd + 1) * per_xcd : ntiles);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (F64) {
+    for (int c = tid; c <= n_hash; c += K2_THREADS) ratio_tab[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
+    __syncthreads();
+  }
+  const PlaneGeom pg = plane_geom(n, n_hash, PL);
+  // wave-uniform DMA source: wave w stages LDS slots [64w, 64w + 64) of a stage = rows (w < 2) or columns (w >= 2) of the
+  // tile, 3 KiB per stage; the operand is stored in staging order, so block b of an operand starts b * nst * 6144 bytes in
+  const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)wave);
+  const uint64_t block_bytes = (uint64_t)pg.nst * (128u * PL * 4u);
+  const uint64_t wave_base = reinterpret_cast<uint64_t>(planes) + (wave_u >= 2 ? (uint64_t)pg.copy_words * 4u : 0u) + (wave_u & 1u) * 3072u;
+  auto source_of = [&](const TileId &t) -> uint64_t { return wave_base + (uint64_t)(wave_u >= 2 ? t.tj : t.ti) * block_bytes; };
+  auto next_taken = [&](int from, TileId &t) -> int {               // first tile id >= from (stride wg_per_xcd) the asm kernels take
+    for (int L = from; L < lim; L += wg_per_xcd) {
+      int To = T;
+      asm volatile("" : "+s"(To));                              // opaque per call: no float invariants of the decode hoisted into VGPRs
+      t = decode_tile(L, To, To, true);
+      t.ti = __builtin_amdgcn_readfirstlane(t.ti);             // wave-uniform by construction: keep them in SGPRs, nothing
+      t.tj = __builtin_amdgcn_readfirstlane(t.tj);             // per-lane may live across the block (it clobbers the VGPR file)
+      if (t.valid && a12_takes(t.ti, t.tj, n, ld, out_v, F64)) return L;
+    }
+    return lim;
+  };
+  const int tx0 = ((wave & 1) << 3) + (lane & 7), ty0 = ((wave >> 1) << 3) + (lane >> 3);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)lds_ab);
+  const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = 128u * PL * 4u;
+  const uint32_t nn = (uint32_t)n_hash * 0x10001u;             // two match counts per register (no borrow: each <= n_hash)
+  register uint32_t r120 asm("v120") = lds_base + (uint32_t)(ty0 * SEGS * 16);                       // the lane's first row operand inside a stage
+  register uint32_t r121 asm("v121") = lds_base + (uint32_t)((K2_TILE * SEGS + tx0 * SEGS) * 16);   // ... first column operand
+  register uint32_t r124 asm("v124") = (uint32_t)tid * 4u;
+
+#ifdef K2_STAGGER    // experiment: the CU's resident workgroups start a quarter of a tile period apart
+  for (int w = 0; w < ((slot ^ (slot >> 5)) & 3) * K2_STAGGER; ++w) __builtin_amdgcn_s_sleep(127);
+#endif
+  TileId cur, nxt;
+  int L = next_taken((int)((int64_t)xcd * per_xcd) + slot, cur);
+  uint32_t flags = 1u, phase = 0u;                             // bit 0: first tile of this workgroup; ring slot of the tile's stage 0
+#ifdef DA_K2_TIMING
+  int it_stamp = 0;
+#define K2P_STAMP(j) do { if (g_k2_timing && threadIdx.x == 0 && it_stamp < 64) \
+    g_k2_timing[((size_t)blockIdx.x * 64 + it_stamp) * 4 + (j)] = wall_clock64(); } while (0)
+#else
+#define K2P_STAMP(j) do { } while (0)
+#endif
+  while (L < lim) {
+    K2P_STAMP(0);
+    const int Ln = next_taken(L + wg_per_xcd, nxt);
+    if (Ln < lim) flags |= 2u;
+    const uint64_t src = source_of(cur), src_n = source_of(nxt);
+    const uint32_t sl = __builtin_amdgcn_readfirstlane((uint32_t)src), sh = __builtin_amdgcn_readfirstlane((uint32_t)(src >> 32));
+    const uint32_t nl = __builtin_amdgcn_readfirstlane((uint32_t)src_n), nh = __builtin_amdgcn_readfirstlane((uint32_t)(src_n >> 32));
+    const uint32_t fl = __builtin_amdgcn_readfirstlane(flags), sp = __builtin_amdgcn_readfirstlane(phase * (uint32_t)(STAGE_UNITS * 16));
+    uint32_t mis[8][4];
+    uint32_t tid_after;
+    K2P_STAMP(1);
+    {
+#define K2_CNT(i) register uint32_t c##i asm("v" #i);
+      K2_CNT(64) K2_CNT(65) K2_CNT(66) K2_CNT(67) K2_CNT(68) K2_CNT(69) K2_CNT(70) K2_CNT(71) K2_CNT(72) K2_CNT(73) K2_CNT(74)
+      K2_CNT(75) K2_CNT(76) K2_CNT(77) K2_CNT(78) K2_CNT(79) K2_CNT(80) K2_CNT(81) K2_CNT(82) K2_CNT(83) K2_CNT(84) K2_CNT(85)
+      K2_CNT(86) K2_CNT(87) K2_CNT(88) K2_CNT(89) K2_CNT(90) K2_CNT(91) K2_CNT(92) K2_CNT(93) K2_CNT(94) K2_CNT(95)
+#undef K2_CNT
+      asm volatile(
+#include K2_LOOP_INC_P
+          : "=v"(c64), "=v"(c65), "=v"(c66), "=v"(c67), "=v"(c68), "=v"(c69), "=v"(c70), "=v"(c71), "=v"(c72), "=v"(c73), "=v"(c74),
+            "=v"(c75), "=v"(c76), "=v"(c77), "=v"(c78), "=v"(c79), "=v"(c80), "=v"(c81), "=v"(c82), "=v"(c83), "=v"(c84), "=v"(c85),
+            "=v"(c86), "=v"(c87), "=v"(c88), "=v"(c89), "=v"(c90), "=v"(c91), "=v"(c92), "=v"(c93), "=v"(c94), "=v"(c95)
+          : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh), [nl] "s"(nl),
+            [nh] "s"(nh), [fl] "s"(fl), [sp] "s"(sp), "v"(r120), "v"(r121), "v"(r124)
+          : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",   // m0 is saved in s47 and restored by the block
+            "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+            "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
+            "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+            "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",
+            "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+            "v117", "v118", "v119", "v122", "v123");
+      asm volatile("" : "+v"(r124));                             // lane ids are re-derived from the value that crossed the block
+      tid_after = r124 >> 2;
+      const uint32_t cnt[32] = {c64, c65, c66, c67, c68, c69, c70, c71, c72, c73, c74, c75, c76, c77, c78, c79,
+                                c80, c81, c82, c83, c84, c85, c86, c87, c88, c89, c90, c91, c92, c93, c94, c95};
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mis[r][c] = cnt[4 * r + c];
+    }
+    K2P_STAMP(2);
+    const int wave_e = (int)tid_after >> 6, lane_e = (int)tid_after & 63;
+    const int tx = ((wave_e & 1) << 3) + (lane_e & 7), ty = ((wave_e >> 1) << 3) + (lane_e >> 3);
+    const int64_t I0 = (int64_t)cur.ti * K2_TILE, J0 = (int64_t)cur.tj * K2_TILE;
+#ifdef K2_NO_STORES
+    if (mis[0][0] == 0xdeadbeefu) reinterpret_cast<uint32_t *>(out_v)[0] = tid_after;
+    if (n_hash > 0) { cur = nxt; L = Ln; flags = 0u; phase = (phase + nstage) % 3u; continue; }
+#endif
+    if (F64) {
+      const char *tb = reinterpret_cast<const char *>(ratio_tab);
+      double *out = reinterpret_cast<double *>(out_v);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                              // two of the lane's rows at a time keeps the epilogue in 128 VGPRs
+        double v0[8], v1[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t m0 = nn - mis[2 * g][c], m1 = nn - mis[2 * g + 1][c];
+          v0[2 * c] = *reinterpret_cast<const double *>(tb + ((m0 << 3) & 0x7fff8u));
+          v0[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m0 >> 13) & 0x7fff8u));
+          v1[2 * c] = *reinterpret_cast<const double *>(tb + ((m1 << 3) & 0x7fff8u));
+          v1[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m1 >> 13) & 0x7fff8u));
+        }
+        double *orow = out + (I0 + 32 * g + 2 * ty) * ld + (J0 + 2 * tx);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          nt_store2(orow + 32 * q, v0[2 * q], v0[2 * q + 1]);
+          nt_store2(orow + ld + 32 * q, v1[2 * q], v1[2 * q + 1]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)                              // mirrored store (src/minHash.cpp:176)
+          nt_store2(out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 32 * g + 2 * ty), v0[c], v1[c]);
+      }
+    } else {
+      uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint16_t *orow = out + (I0 + 32 * (r >> 1) + 2 * ty + (r & 1)) * ld + (J0 + 2 * tx);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - mis[r][g];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        uint16_t *orow = out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 2 * ty);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t lo = mis[2 * g][c >> 1], hi = mis[2 * g + 1][c >> 1];
+          const uint32_t pk = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+          *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - pk;
+        }
+      }
+    }
+    K2P_STAMP(3);
+#ifdef DA_K2_TIMING
+    ++it_stamp;
+#endif
+    cur = nxt;
+    L = Ln;
+    flags = 0u;
+    phase = (phase + nstage) % 3u;
+  }
+#undef K2P_STAMP
 }
 
 // PL = bit planes per group of 32 hash functions: 32 (raw uint32 values) or 16 / 12 / 8 (dictionary
@@ -904,7 +1087,39 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   const bool a12 = symmetric && plane_bits == 12 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
                    (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A12_TABLE_MAX) &&
                    (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;   // = a12_takes' alignment test
-  if (a12) {
+  // the persistent form of that kernel: >= 2 stages per tile, float64 needs its 4 KiB table (n_hash <= 511)
+  // OPT-IN (DYNAALIGN_K2_PERSIST=1): measured slower than one tile per workgroup on MI355X -- 28.8 vs 24.9 ms (float64),
+  // 26.3 vs 22.2 ms (uint16) at N = 100k (profiles/r02_c_k2_persistent_*.json): a wave that does not exit has to
+  // wait for its own stores (vmcnt is in order), and a CU drains only ~20 GB/s of stores, so the 256 KiB of a tile take
+  // ~13 us either way; with one tile per workgroup that time is spent by an exiting workgroup while the slot's successor
+  // already loads.  Kept because it is bit-exact, tested, and the structure the next step needs (stores interleaved into
+  // the following tile's stage loop).
+  const bool p12 = a12 && n_hash > K2_GROUP && (kind != DA_OUT_F64 || n_hash < K2_P12_TABLE) && getenv("DYNAALIGN_K2_PERSIST");
+  if (p12) {
+    static int occ_cache[2] = {0, 0}, cus_cache = 0;              // resident workgroups per CU (4 expected), CUs of the device
+    const int ki = kind == DA_OUT_F64 ? 0 : 1;
+    if (!occ_cache[ki]) {
+      int occ = 0;
+      if (ki == 0) DA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mh_compare_p12<true>, K2_THREADS, 0));
+      else DA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mh_compare_p12<false>, K2_THREADS, 0));
+      int dev = 0;
+      hipDeviceProp_t prop;
+      DA_HIP_TRY(hipGetDevice(&dev));
+      DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+      if (const char *e = getenv("DYNAALIGN_K2_WG_PER_CU")) occ = atoi(e);
+      occ_cache[ki] = occ > 0 ? occ : 1;
+      cus_cache = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      if (getenv("DYNAALIGN_TRACE"))
+        fprintf(stderr, "[dynaalign] k_mh_compare_p12<%s>: %d resident workgroups per CU, %d CUs\n", ki == 0 ? "f64" : "u16", occ_cache[ki], cus_cache);
+    }
+    int wg_per_xcd = occ_cache[ki] * ((cus_cache + 7) / 8);
+    if ((int64_t)wg_per_xcd > per_xcd) wg_per_xcd = (int)(per_xcd > 0 ? per_xcd : 1);
+    const dim3 pgrid((unsigned)(8 * wg_per_xcd));
+    if (kind == DA_OUT_F64)
+      hipLaunchKernelGGL(k_mh_compare_p12<true>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd);
+    else
+      hipLaunchKernelGGL(k_mh_compare_p12<false>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd);
+  } else if (a12) {
     if (kind == DA_OUT_F64)
       hipLaunchKernelGGL(k_mh_compare_a12<true>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
     else

@@ -14,6 +14,8 @@ import pytest
 
 import oracle_lib as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -224,29 +226,59 @@ def test_crafted_signature_columns(da, n):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,n_hash", [(1000, 500), (1153, 70), (2048, 33), (640, 31)])
+@pytest.mark.parametrize("n,n_hash", [(1000, 500), (1153, 70), (2048, 33), (640, 31), (2500, 64), (3001, 129), (1300, 511), (1300, 512),
+                                      (5000, 500)])
 def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash):
-    """symmetric 12-plane compares run the hand-scheduled stage loop on interior tiles (k_mh_compare_a12) and the
-    compiled kernel on diagonal / border tiles; DYNAALIGN_K2_NO_ASM=1 runs the compiled kernel everywhere.  Both
-    outputs, both output kinds, 1 / 2 / 3 / 16 stages, n a multiple of 128 or not."""
+    """symmetric 12-plane compares run a hand-scheduled stage loop on interior tiles and the compiled kernel on diagonal /
+    border tiles.  Three routes, same operand: the one-tile-per-workgroup k_mh_compare_a12 (default), the PERSISTENT kernel
+    k_mh_compare_p12 (DYNAALIGN_K2_PERSIST=1; a workgroup walks a sequence of tiles, ring never drains; n_hash <= 32 and
+    float64 n_hash >= 512 fall back to a12 by themselves) and the compiled kernel everywhere (DYNAALIGN_K2_NO_ASM=1).  Both
+    output kinds, 1 / 2 / 3 / 5 / 16 stages (ring phases 0, 1, 2 between tiles), n a multiple of 128 or not, few tiles per
+    workgroup (n = 1000) and many (n = 5000: 780 tiles over 1024 workgroups -> some get one tile, some none)."""
     import torch
     from dynaalign_amd import device, synth, _capi
     res, off = synth.h3n2_like(n, 20)
     n, sig_h, p12, p32 = _planes_both(da, res, off, 4, n_hash, min_bits=12)
     assert p12.bits == 12
-    want = _counts(sig_h)
+    want = _counts(sig_h) if n <= 3100 else None
     got = {}
-    for tag in ("asm", "compiled"):
-        if tag == "compiled":
-            os.environ["DYNAALIGN_K2_NO_ASM"] = "1"
+    for tag, env in (("persistent", "DYNAALIGN_K2_PERSIST"), ("one_tile", None), ("compiled", "DYNAALIGN_K2_NO_ASM")):
+        if env:
+            os.environ[env] = "1"
         try:
             got[tag] = (device.mh_compare(p12, n, n_hash, kind=_capi.DA_OUT_COMPACT).cpu().numpy().view(np.uint16),
                         device.mh_compare(p12, n, n_hash).cpu().numpy())
         finally:
-            os.environ.pop("DYNAALIGN_K2_NO_ASM", None)
-    assert np.array_equal(got["asm"][0], want) and np.array_equal(got["compiled"][0], want)
-    assert np.array_equal(got["asm"][1].view(np.uint64), got["compiled"][1].view(np.uint64))
-    assert np.array_equal(got["asm"][1], want.astype(np.float64) / n_hash)
+            if env:
+                os.environ.pop(env, None)
+    for tag in ("persistent", "one_tile"):
+        assert np.array_equal(got[tag][0], got["compiled"][0]), tag
+        assert np.array_equal(got[tag][1].view(np.uint64), got["compiled"][1].view(np.uint64)), tag
+    if want is not None:
+        assert np.array_equal(got["compiled"][0], want)
+        assert np.array_equal(got["compiled"][1], want.astype(np.float64) / n_hash)
+
+
+@pytest.mark.parametrize("wg_per_cu", [1, 2, 3])
+def test_persistent_kernel_with_few_workgroups(da, wg_per_cu):
+    """fewer resident workgroups (as when the occupancy query answers less than 4): every workgroup walks a longer tile
+    sequence; results must not depend on the grid"""
+    import subprocess, sys
+    code = (
+        "import os, sys; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import numpy as np, torch, dynaalign_amd as da\n"
+        "from dynaalign_amd import device, synth, _capi\n"
+        "res, off = synth.h3n2_like(9000, 20)\n"
+        "ds = device.DeviceSequences(res, off)\n"
+        "sig, p = device.minhash_signatures(ds, 4, 500, da.hash_family_seeds(12345, 500), min_plane_bits=12)\n"
+        "a = device.mh_compare(p, 9000, 500); a16 = device.mh_compare(p, 9000, 500, kind=_capi.DA_OUT_COMPACT)\n"
+        "os.environ['DYNAALIGN_K2_NO_ASM'] = '1'\n"
+        "b = device.mh_compare(p, 9000, 500); b16 = device.mh_compare(p, 9000, 500, kind=_capi.DA_OUT_COMPACT)\n"
+        "assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and torch.equal(a16, b16)\n"
+        "print('ok')\n") % (ROOT, ROOT)
+    env = dict(os.environ, DYNAALIGN_K2_WG_PER_CU=str(wg_per_cu), DYNAALIGN_K2_PERSIST="1")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=300)
+    assert out.decode().strip().endswith("ok")
 
 
 @pytest.mark.parametrize("n_hash", [4607, 4608, 7000])

@@ -24,3 +24,20 @@ def test_committed_include_is_the_generators_output(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
                           stdout=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p12.inc")).read()
+
+
+@pytest.mark.parametrize("ntiles,ns,tx,ty", [(1, 16, 0, 0), (2, 16, 5, 11), (3, 16, 15, 15), (4, 2, 7, 8), (3, 3, 1, 2), (5, 5, 9, 4), (2, 17, 3, 3)])
+def test_persistent_block_over_a_tile_sequence(ntiles, ns, tx, ty):
+    """the block of k_mh_compare_p12, called ntiles times on one LDS ring: first / has-next flags, ring phase, source switch"""
+    import sim_k2_asm
+    issued, bad = sim_k2_asm.run_persistent(tx, ty, seed=ntiles * 100 + ns, ntiles=ntiles, ns=ns)
+    assert issued == ntiles * ns and bad == 0
+
+
+def test_committed_persistent_include_is_the_generators_output(tmp_path):
+    out = tmp_path / "k2p.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("K2ASM_")}
+    env["K2ASM_PERSIST"] = "1"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
+                          stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p12p.inc")).read()

@@ -26,6 +26,14 @@ SAFE = int(os.environ.get("K2ASM_SAFE", "0"))   # debugging: 1 = drain after eve
 REGOUT = int(os.environ.get("K2ASM_REGOUT", "1"))   # 1: the 32 packed counters leave the block in v64..v95 (asm outputs);
 # 0: through LDS (barrier + 32 ds_write_b32 + wait, read back by the C++ epilogue -- the first version: +1 us per tile)
 
+PERSIST = int(os.environ.get("K2ASM_PERSIST", "0"))   # 1: the block of the PERSISTENT kernel (k_mh_compare_p12): one tile of a
+# workgroup's tile sequence -- the ring never drains between tiles.  Extra operands: %[fl] flags (bit 0: first tile of the
+# workgroup = issue stages 0 and 1 here; bit 1: another tile follows = issue ITS stages 0 and 1 during the last two stages
+# and wait for them before leaving), %[nl]:%[nh] the wave's source base of the next tile, %[sp] ring byte offset of stage 0.
+# Always with the SGPR-base DMA form (the tile switch is two s_mov).
+if PERSIST:
+    SADDR = 1
+    REGOUT = 1
 SEGS, STEPS = 3, 6           # 12 planes: 3 segments of 16 bytes = 6 steps of 8 bytes
 STAGE_BYTES = 256 * SEGS * 16  # 12288
 ROW = 16 * SEGS * 16          # byte distance between the lane's rows / columns in LDS: 768
@@ -127,114 +135,237 @@ def step(k, first, last, cur):
         cur = (cur + 1) % 3
     return cur
 
-e("// generated by tools/gen_k2_asm.py -- do not edit")
-e("s_mov_b32 s47, m0")                                # m0 is compiler-reserved: saved here, restored at the end of the block
-if PRIO:
-    e("s_setprio %d" % PRIO)
-# ---- setup
-e("s_mov_b32 %s, 0" % S_STAGE)                       # stage being computed
-e("s_sub_u32 %s, %%[st], 2048" % S_LEFT)               # the running DMA source sits 2 KiB into the stage it last issued
-if SADDR:
-    e("s_mov_b32 s48, %[sl]")               # the wave's first source address (lane 0) as the scalar base ...
-    e("s_mov_b32 s49, %[sh]")
-    e("v_and_b32 v118, 0xfc, v124")         # ... and 16 * lane as the per-lane offset
-    e("v_lshlrev_b32 v118, 2, v118")
-else:
-    e("v_mov_b32 v118, v122")
-    e("v_mov_b32 v119, v123")
-for r in range(8):
-    for c2 in range(4):
-        e("v_mov_b32 %s, 0" % mis(r, c2))
-# LDS DMA offset of this wave inside a stage: wave * 3 KiB (the wave id comes in as an SGPR operand)
-e("s_mul_i32 %s, %%[wv], 3072" % S_TMP)
-e("s_add_u32 s46, %[lb], " + S_TMP)                 # s46 = ring + wave part (slot 0)
-# issue stages 0 and 1
-e("s_mov_b32 %s, s46" % S_M0)
-issue("0")
-e("s_cmp_lt_u32 1, %[ns]")
-e("s_cbranch_scc0 1f")
-if SADDR:
+
+def wrap_slot(reg):
+    """reg (a ring byte offset that was just advanced by one or two stages) back into [0, 3 stages)"""
+    e("s_cmp_lt_u32 %s, %d" % (reg, 3 * STAGE_BYTES))
+    e("s_cbranch_scc1 8f")
+    e("s_sub_u32 %s, %s, %d" % (reg, reg, 3 * STAGE_BYTES))
+    e("8:")
+
+def issue_saddr():
+    """DMA of one stage from the wave's running base s[48:49] (three 1 KiB pieces), then advance the base by a stage"""
+    for q in range(3):
+        e("s_add_u32 m0, %s, %d" % (S_M0, q * 1024))
+        e("s_add_u32 s50, s48, %d" % (q * 1024))
+        e("s_addc_u32 s51, s49, 0")
+        e("global_load_lds_dwordx4 v118, s[50:51]")
     e("s_add_u32 s48, s48, %[st]")
     e("s_addc_u32 s49, s49, 0")
-else:
-    e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
-    e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
-e("s_add_u32 %s, s46, %d" % (S_M0, STAGE_BYTES))
-issue("1")
-e("1:")
-e("s_mov_b32 %s, 0" % S_SLOT)                        # ring slot of the stage being computed (byte offset)
-e("s_mov_b32 %s, %d" % (S_ISSUE_SLOT, 2 * STAGE_BYTES))  # ring slot the next issue goes to
-# ---- stage loop
-e("2:")
-e("s_add_u32 %s, %s, 1" % (S_TMP, S_STAGE))
-e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)                  # is there a younger stage in flight?
-e("s_cbranch_scc0 3f")
-e("s_waitcnt vmcnt(3)")
-e("s_branch 4f")
-e("3:")
-e("s_waitcnt vmcnt(0)")
-e("4:")
-e("s_barrier")
-# LDS read bases of this stage
-e("v_add_u32 v116, %s, v120" % S_SLOT)
-e("v_add_u32 v117, %s, v121" % S_SLOT)
-# preload step 0 operands: b(col 0), b(col 1), then the 8 row operands (the order step() counts on)
-b_read(0, 0, 0)
-b_read(1, 0, 1)
-for r in range(8):
-    e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
-# issue stage + 2 while those reads fly
-if SPREAD:
-    issue_piece(0)
-else:
+
+def gen_persistent():
+    e("// generated by tools/gen_k2_asm.py (K2ASM_PERSIST=1) -- do not edit")
+    e("s_mov_b32 s47, m0")
+    if PRIO:
+        e("s_setprio %d" % PRIO)
+    e("s_mov_b32 %s, 0" % S_STAGE)
+    e("v_and_b32 v118, 0xfc, v124")          # 16 * lane: this lane's offset inside the wave's 1 KiB piece
+    e("v_lshlrev_b32 v118, 2, v118")
+    for r in range(8):
+        for c2 in range(4):
+            e("v_mov_b32 %s, 0" % mis(r, c2))
+    e("s_mul_i32 %s, %%[wv], 3072" % S_TMP)
+    e("s_add_u32 s46, %[lb], " + S_TMP)                 # ring + this wave's part of a stage
+    e("s_mov_b32 %s, %%[sp]" % S_SLOT)                  # ring slot (byte offset) of the stage being computed
+    e("s_add_u32 %s, %%[sp], %d" % (S_ISSUE_SLOT, 2 * STAGE_BYTES))
+    wrap_slot(S_ISSUE_SLOT)                              # ring slot the next issue goes to
+    e("s_mov_b32 s48, %[sl]")
+    e("s_mov_b32 s49, %[sh]")
+    e("s_bitcmp1_b32 %[fl], 0")
+    e("s_cbranch_scc0 10f")
+    # first tile of the workgroup: its stages 0 and 1 are issued here
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_SLOT))
+    issue_saddr()
+    e("s_add_u32 %s, %s, %d" % (S_TMP, S_SLOT, STAGE_BYTES))
+    wrap_slot(S_TMP)
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_TMP))
+    issue_saddr()
+    e("s_branch 11f")
+    e("10:")
+    # later tiles: the previous block issued (and waited for) stages 0 and 1; the running base starts at stage 2
+    e("s_add_u32 s48, s48, %[st]")
+    e("s_addc_u32 s49, s49, 0")
+    e("s_add_u32 s48, s48, %[st]")
+    e("s_addc_u32 s49, s49, 0")
+    e("11:")
+    # ---- stage loop
+    e("2:")
+    e("s_bitcmp1_b32 %[fl], 0")
+    e("s_cbranch_scc1 20f")
+    e("s_cmp_lt_u32 %s, 2" % S_STAGE)
+    e("s_cbranch_scc1 4f")                   # stages 0 / 1 of a later tile landed before the previous tile's stores were issued
+    e("20:")
+    e("s_add_u32 %s, %s, 1" % (S_TMP, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)     # a younger stage of this tile in flight?
+    e("s_cbranch_scc1 21f")
+    e("s_bitcmp1_b32 %[fl], 1")              # ... or stage 0 of the next tile?
+    e("s_cbranch_scc1 21f")
+    e("s_waitcnt vmcnt(0)")
+    e("s_branch 4f")
+    e("21:")
+    e("s_waitcnt vmcnt(3)")
+    e("4:")
+    e("s_barrier")
+    e("v_add_u32 v116, %s, v120" % S_SLOT)
+    e("v_add_u32 v117, %s, v121" % S_SLOT)
+    b_read(0, 0, 0)
+    b_read(1, 0, 1)
+    for r in range(8):
+        e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
+    # issue stage + 2 (of this tile, or stage 0 / 1 of the next one) while those reads fly
     e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
     e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
-    e("s_cbranch_scc0 5f")
+    e("s_cbranch_scc1 30f")
+    e("s_bitcmp1_b32 %[fl], 1")
+    e("s_cbranch_scc0 5f")                   # last tile: nothing left to issue
+    e("s_cmp_eq_u32 %s, %%[ns]" % S_TMP)
+    e("s_cbranch_scc0 30f")                  # stage 1 of the next tile: the base was advanced by the stage-0 issue
+    e("s_mov_b32 s48, %[nl]")                # stage 0 of the next tile: switch the running base
+    e("s_mov_b32 s49, %[nh]")
+    e("30:")
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
+    issue_saddr()
+    e("5:")
+    e("s_cmp_eq_u32 %s, 0" % S_STAGE)
+    e("s_cbranch_scc1 6f")
+    count_group()
+    e("6:")
+    cur = 0
+    for k in range(STEPS):
+        cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)
+    assert cur == 0
+    e("s_add_u32 %s, %s, %d" % (S_SLOT, S_SLOT, STAGE_BYTES))
+    e("s_cmp_lt_u32 %s, %d" % (S_SLOT, 3 * STAGE_BYTES))
+    e("s_cselect_b32 %s, %s, 0" % (S_SLOT, S_SLOT))
+    e("s_add_u32 %s, %s, %d" % (S_ISSUE_SLOT, S_ISSUE_SLOT, STAGE_BYTES))
+    e("s_cmp_lt_u32 %s, %d" % (S_ISSUE_SLOT, 3 * STAGE_BYTES))
+    e("s_cselect_b32 %s, %s, 0" % (S_ISSUE_SLOT, S_ISSUE_SLOT))
+    e("s_add_u32 %s, %s, 1" % (S_STAGE, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
+    e("s_cbranch_scc1 2b")
+    count_group()
+    if PRIO or EPRIO:
+        e("s_setprio %d" % EPRIO)
+    # the next tile's first two stages must have landed before this wave issues the tile's stores (the stage loop
+    # of the next block does not wait for them: vmcnt counts loads and stores together, in order)
+    e("s_bitcmp1_b32 %[fl], 1")
+    e("s_cbranch_scc0 9f")
+    e("s_waitcnt vmcnt(0)")
+    e("9:")
+    e("s_mov_b32 m0, s47")
+
+if PERSIST:
+    gen_persistent()
+else:
+    e("// generated by tools/gen_k2_asm.py -- do not edit")
+    e("s_mov_b32 s47, m0")                                # m0 is compiler-reserved: saved here, restored at the end of the block
+    if PRIO:
+        e("s_setprio %d" % PRIO)
+    # ---- setup
+    e("s_mov_b32 %s, 0" % S_STAGE)                       # stage being computed
+    e("s_sub_u32 %s, %%[st], 2048" % S_LEFT)               # the running DMA source sits 2 KiB into the stage it last issued
+    if SADDR:
+        e("s_mov_b32 s48, %[sl]")               # the wave's first source address (lane 0) as the scalar base ...
+        e("s_mov_b32 s49, %[sh]")
+        e("v_and_b32 v118, 0xfc, v124")         # ... and 16 * lane as the per-lane offset
+        e("v_lshlrev_b32 v118, 2, v118")
+    else:
+        e("v_mov_b32 v118, v122")
+        e("v_mov_b32 v119, v123")
+    for r in range(8):
+        for c2 in range(4):
+            e("v_mov_b32 %s, 0" % mis(r, c2))
+    # LDS DMA offset of this wave inside a stage: wave * 3 KiB (the wave id comes in as an SGPR operand)
+    e("s_mul_i32 %s, %%[wv], 3072" % S_TMP)
+    e("s_add_u32 s46, %[lb], " + S_TMP)                 # s46 = ring + wave part (slot 0)
+    # issue stages 0 and 1
+    e("s_mov_b32 %s, s46" % S_M0)
+    issue("0")
+    e("s_cmp_lt_u32 1, %[ns]")
+    e("s_cbranch_scc0 1f")
     if SADDR:
         e("s_add_u32 s48, s48, %[st]")
         e("s_addc_u32 s49, s49, 0")
     else:
         e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
         e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
-    e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
-    issue("st+2")
-    e("5:")
-# popcounts of the previous group (skipped for stage 0) while the reads fly
-e("s_cmp_eq_u32 %s, 0" % S_STAGE)
-e("s_cbranch_scc1 6f")
-count_group()
-e("6:")
-# the 6 steps.  NOTE: every step starts with b in buffer 0: 8 columns -> the buffer index is back at 0 after a step
-cur = 0
-for k in range(STEPS):
-    if SPREAD and k in (2, 4):
-        issue_piece(k // 2)
-    cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)
-# 6 steps x 8 columns = 48 buffer advances = 0 mod 3: the next stage starts with buffer 0 again
-assert cur == 0
-# advance
-e("s_add_u32 %s, %s, %d" % (S_SLOT, S_SLOT, STAGE_BYTES))
-e("s_cmp_lt_u32 %s, %d" % (S_SLOT, 3 * STAGE_BYTES))
-e("s_cselect_b32 %s, %s, 0" % (S_SLOT, S_SLOT))
-e("s_add_u32 %s, %s, %d" % (S_ISSUE_SLOT, S_ISSUE_SLOT, STAGE_BYTES))
-e("s_cmp_lt_u32 %s, %d" % (S_ISSUE_SLOT, 3 * STAGE_BYTES))
-e("s_cselect_b32 %s, %s, 0" % (S_ISSUE_SLOT, S_ISSUE_SLOT))
-e("s_add_u32 %s, %s, 1" % (S_STAGE, S_STAGE))
-e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
-e("s_cbranch_scc1 2b")
-count_group()
-# ---- counters -> LDS (plane k of the write-back area = 1 KiB of lane-consecutive dwords), after everyone left the ring
-if PRIO or EPRIO:
-    e("s_setprio %d" % EPRIO)
-if not REGOUT:
+    e("s_add_u32 %s, s46, %d" % (S_M0, STAGE_BYTES))
+    issue("1")
+    e("1:")
+    e("s_mov_b32 %s, 0" % S_SLOT)                        # ring slot of the stage being computed (byte offset)
+    e("s_mov_b32 %s, %d" % (S_ISSUE_SLOT, 2 * STAGE_BYTES))  # ring slot the next issue goes to
+    # ---- stage loop
+    e("2:")
+    e("s_add_u32 %s, %s, 1" % (S_TMP, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)                  # is there a younger stage in flight?
+    e("s_cbranch_scc0 3f")
+    e("s_waitcnt vmcnt(3)")
+    e("s_branch 4f")
+    e("3:")
+    e("s_waitcnt vmcnt(0)")
+    e("4:")
     e("s_barrier")
-if not DUMP and not REGOUT:
-    e("v_add_u32 v125, %[lb], v124")
+    # LDS read bases of this stage
+    e("v_add_u32 v116, %s, v120" % S_SLOT)
+    e("v_add_u32 v117, %s, v121" % S_SLOT)
+    # preload step 0 operands: b(col 0), b(col 1), then the 8 row operands (the order step() counts on)
+    b_read(0, 0, 0)
+    b_read(1, 0, 1)
     for r in range(8):
-        for c2 in range(4):
-            e("ds_write_b32 v125, %s offset:%d" % (mis(r, c2), (4 * r + c2) * 1024))
-    e("s_waitcnt lgkmcnt(0)")
-e("s_mov_b32 m0, s47")
+        e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
+    # issue stage + 2 while those reads fly
+    if SPREAD:
+        issue_piece(0)
+    else:
+        e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
+        e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
+        e("s_cbranch_scc0 5f")
+        if SADDR:
+            e("s_add_u32 s48, s48, %[st]")
+            e("s_addc_u32 s49, s49, 0")
+        else:
+            e("v_add_co_u32 v118, vcc, %s, v118" % S_LEFT)
+            e("v_addc_co_u32 v119, vcc, 0, v119, vcc")
+        e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
+        issue("st+2")
+        e("5:")
+    # popcounts of the previous group (skipped for stage 0) while the reads fly
+    e("s_cmp_eq_u32 %s, 0" % S_STAGE)
+    e("s_cbranch_scc1 6f")
+    count_group()
+    e("6:")
+    # the 6 steps.  NOTE: every step starts with b in buffer 0: 8 columns -> the buffer index is back at 0 after a step
+    cur = 0
+    for k in range(STEPS):
+        if SPREAD and k in (2, 4):
+            issue_piece(k // 2)
+        cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)
+    # 6 steps x 8 columns = 48 buffer advances = 0 mod 3: the next stage starts with buffer 0 again
+    assert cur == 0
+    # advance
+    e("s_add_u32 %s, %s, %d" % (S_SLOT, S_SLOT, STAGE_BYTES))
+    e("s_cmp_lt_u32 %s, %d" % (S_SLOT, 3 * STAGE_BYTES))
+    e("s_cselect_b32 %s, %s, 0" % (S_SLOT, S_SLOT))
+    e("s_add_u32 %s, %s, %d" % (S_ISSUE_SLOT, S_ISSUE_SLOT, STAGE_BYTES))
+    e("s_cmp_lt_u32 %s, %d" % (S_ISSUE_SLOT, 3 * STAGE_BYTES))
+    e("s_cselect_b32 %s, %s, 0" % (S_ISSUE_SLOT, S_ISSUE_SLOT))
+    e("s_add_u32 %s, %s, 1" % (S_STAGE, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
+    e("s_cbranch_scc1 2b")
+    count_group()
+    # ---- counters -> LDS (plane k of the write-back area = 1 KiB of lane-consecutive dwords), after everyone left the ring
+    if PRIO or EPRIO:
+        e("s_setprio %d" % EPRIO)
+    if not REGOUT:
+        e("s_barrier")
+    if not DUMP and not REGOUT:
+        e("v_add_u32 v125, %[lb], v124")
+        for r in range(8):
+            for c2 in range(4):
+                e("ds_write_b32 v125, %s offset:%d" % (mis(r, c2), (4 * r + c2) * 1024))
+        e("s_waitcnt lgkmcnt(0)")
+    e("s_mov_b32 m0, s47")
+
 
 with open(sys.argv[1], "w") as f:
     for l in out:

@@ -15,6 +15,117 @@ import sys
 INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynaalign_amd", "csrc", "k2_loop_p12.inc")
 
 
+INC_P = os.path.join(os.path.dirname(INC), "k2_loop_p12p.inc")
+
+
+def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P):
+    """The block of the persistent kernel (K2ASM_PERSIST=1), executed `ntiles` times in a row on one LDS image, the
+    way k_mh_compare_p12 calls it: flags first / has-next, ring phase advancing by ns stages per tile, the next tile's
+    source handed in.  The DMA is modelled by ADDRESS: the stage image that appears in the ring is the one the running
+    source base points at, so a wrong base switch or ring slot shows up as wrong counters.  Returns (stages issued,
+    wrong counters)."""
+    lines = [l.strip()[1:].split('\\n')[0] for l in open(inc) if l.startswith('"')]
+    STAGE = 12288; LB = 4096; ST = 6144; TILE_STRIDE = 1 << 24
+    random.seed(seed)
+    stages = [[bytes(random.getrandbits(8) for _ in range(STAGE)) for _ in range(ns)] for _ in range(ntiles)]
+    lds = bytearray(LB + 3 * STAGE)
+    labels = {}
+    for i, l in enumerate(lines):
+        m = re.match(r'^(\d+):$', l)
+        if m: labels.setdefault(m.group(1), []).append(i)
+    issued_total = 0
+    bad = 0
+    phase = 0
+    for t in range(ntiles):
+        V = [0] * 256; S = {}
+        S['lb'] = LB; S['ns'] = ns; S['st'] = ST; S['wv'] = 0
+        S['fl'] = (1 if t == 0 else 0) | (2 if t + 1 < ntiles else 0)
+        S['sp'] = phase * STAGE
+        base = (t + 1) * TILE_STRIDE; nbase = (t + 2) * TILE_STRIDE
+        S['sl'], S['sh'] = base & 0xffffffff, base >> 32
+        S['nl'], S['nh'] = nbase & 0xffffffff, nbase >> 32
+        V[120] = LB + ty * 48; V[121] = LB + (128 * 3 + tx * 3) * 16; V[124] = 0
+        def sval(x):
+            x = x.strip()
+            if x.startswith('%['): return S[x[2:-1]]
+            if x == 'm0': return S.get('m0', 0)
+            if x.startswith('s'): return S.get(x, 0)
+            return int(x, 0)
+        def vreg(x): return int(x.strip()[1:])
+        def vpair(x): return int(re.match(r'v\[(\d+):(\d+)\]', x.strip()).group(1))
+        pc = 0; scc = 0; piece = 0
+        while pc < len(lines):
+            l = lines[pc]; pc += 1
+            if re.match(r'^\d+:$', l) or l.startswith('//') or not l: continue
+            op, _, rest = l.partition(' ')
+            a = [x.strip() for x in rest.split(',')] if rest else []
+            if op == 's_mov_b32': S[a[0]] = sval(a[1])
+            elif op == 's_add_u32':
+                r = sval(a[1]) + sval(a[2]); S[a[0]] = r & 0xffffffff; scc = int(r > 0xffffffff)
+            elif op == 's_addc_u32':
+                r = sval(a[1]) + sval(a[2]) + scc; S[a[0]] = r & 0xffffffff; scc = int(r > 0xffffffff)
+            elif op == 's_sub_u32': S[a[0]] = (sval(a[1]) - sval(a[2])) & 0xffffffff
+            elif op == 's_mul_i32': S[a[0]] = (sval(a[1]) * sval(a[2])) & 0xffffffff
+            elif op == 's_cmp_lt_u32': scc = int(sval(a[0]) < sval(a[1]))
+            elif op == 's_cmp_eq_u32': scc = int(sval(a[0]) == sval(a[1]))
+            elif op == 's_bitcmp1_b32': scc = (sval(a[0]) >> sval(a[1])) & 1
+            elif op == 's_cselect_b32': S[a[0]] = sval(a[1]) if scc else sval(a[2])
+            elif op in ('s_cbranch_scc0', 's_cbranch_scc1', 's_branch'):
+                take = (op == 's_branch') or (op == 's_cbranch_scc0' and not scc) or (op == 's_cbranch_scc1' and scc)
+                if take:
+                    num, d = a[0][:-1], a[0][-1]
+                    cands = labels[num]
+                    pc = min(c for c in cands if c >= pc) if d == 'f' else max(c for c in cands if c < pc)
+            elif op in ('s_nop', 's_waitcnt', 's_barrier', 's_setprio'): pass
+            elif op == 'v_mov_b32': V[vreg(a[0])] = V[vreg(a[1])] if a[1].startswith('v') else int(a[1], 0)
+            elif op == 'v_and_b32': V[vreg(a[0])] = int(a[1], 0) & V[vreg(a[2])]
+            elif op == 'v_lshlrev_b32': V[vreg(a[0])] = (V[vreg(a[2])] << int(a[1])) & 0xffffffff
+            elif op == 'global_load_lds_dwordx4':
+                m = re.match(r's\[(\d+):(\d+)\]', a[1])
+                addr = S['s' + m.group(1)] | (S['s' + m.group(2)] << 32)
+                if piece == 0:
+                    tt, off = addr // TILE_STRIDE - 1, addr % TILE_STRIDE
+                    assert off % ST == 0 and 0 <= tt < ntiles and off // ST < ns, "DMA source outside any stage: %x" % addr
+                    slot, rem = divmod(S['m0'] - LB, STAGE)
+                    assert rem == 0 and 0 <= slot < 3, "DMA destination outside the ring: %x" % S['m0']
+                    lds[LB + slot * STAGE:LB + (slot + 1) * STAGE] = stages[tt][off // ST]
+                    issued_total += 1
+                else:
+                    assert addr % TILE_STRIDE % ST == piece * 1024
+                piece = (piece + 1) % 3
+            elif op == 'v_add_u32':
+                x = sval(a[1]) if not a[1].startswith('v') else V[vreg(a[1])]
+                V[vreg(a[0])] = (x + V[vreg(a[2])]) & 0xffffffff
+            elif op == 'ds_read_b64':
+                b = vpair(a[0]); addr = V[vreg(a[1].split()[0])]; off = int(re.search(r'offset:(\d+)', l).group(1))
+                ad = addr + off
+                V[b] = int.from_bytes(lds[ad:ad + 4], 'little'); V[b + 1] = int.from_bytes(lds[ad + 4:ad + 8], 'little')
+            elif op == 'v_xor_b32': V[vreg(a[0])] = V[vreg(a[1])] ^ V[vreg(a[2])]
+            elif op == 'v_bitop3_b32':
+                d_, s0, s1, s2 = vreg(a[0]), vreg(a[1]), vreg(a[2]), vreg(a[3].split()[0])
+                V[d_] = V[s0] | (V[s1] ^ V[s2])
+            elif op == 'v_bcnt_u32_b32':
+                x = V[vreg(a[2])] if a[2].startswith('v') else int(a[2], 0)
+                V[vreg(a[0])] = bin(V[vreg(a[1])]).count('1') + x
+            elif op == 'v_lshl_add_u32': V[vreg(a[0])] = ((V[vreg(a[1])] << int(a[2])) + V[vreg(a[3])]) & 0xffffffff
+            else:
+                raise RuntimeError("unhandled instruction: " + l)
+        def word(stage, slot, w):
+            o = slot * 48 + w * 4; return int.from_bytes(stages[t][stage][o:o + 4], 'little')
+        for r in range(8):
+            for c in range(8):
+                arow = r * 16 + ty; bcol = 128 + c * 16 + tx
+                mism = 0
+                for st in range(ns):
+                    dd = 0
+                    for pl in range(12):
+                        dd |= word(st, arow, pl) ^ word(st, bcol, pl ^ 1)
+                    mism += bin(dd).count('1')
+                if ((V[64 + 4 * r + c // 2] >> (16 * (c & 1))) & 0xffff) != mism: bad += 1
+        phase = (phase + ns) % 3
+    return issued_total, bad
+
+
 def run(tx=5, ty=11, seed=1, inc=INC):
     lines=[l.strip()[1:].split('\\n')[0] for l in open(inc) if l.startswith('"')]
     NS=16; STAGE=12288; LB=0; ST=6144
@@ -114,4 +225,6 @@ def run(tx=5, ty=11, seed=1, inc=INC):
 if __name__ == "__main__":
     issued, bad = run()
     print("stages issued", issued, "wrong counters", bad)
-    sys.exit(1 if bad or issued != 16 else 0)
+    pissued, pbad = run_persistent()
+    print("persistent block, 3 tiles: stages issued", pissued, "wrong counters", pbad)
+    sys.exit(1 if bad or issued != 16 or pbad or pissued != 48 else 0)
