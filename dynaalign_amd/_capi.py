@@ -27,6 +27,7 @@ SIGNATURES = {
     "da_status_message": (C.c_char_p, [_i32]),
     "da_abi_version": (_i32, []),
     "da_device_count": (_i32, []),
+    "da_release_device_memory": (_sz, []),
     "da_hash_family_seeds": (_i32, [_u32, _i32, _vp]),
     "da_random_seed": (_u32, []),
     "da_similarity_mh": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),

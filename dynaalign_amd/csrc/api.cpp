@@ -42,18 +42,75 @@ int fail(int code, const char *fmt, ...) {
 
 namespace {
 
+// Large device buffers are kept for the next call instead of going back to the driver: hipMalloc / hipFree of the
+// 80 GB result buffer cost up to 3.2 s every other call on MI355X (profiles/r02_b_host_path_trace.txt) -- more than the
+// 1.5 s the PCIe copy of the result takes -- and clusterbreak calls sim_fn again and again.  At most two buffers per
+// device are parked; da_release_device_memory() returns them to the driver.
+struct BigCache {
+  static constexpr size_t MIN_BYTES = (size_t)256 << 20;
+  struct Ent { int dev; void *p; size_t bytes; };
+  std::mutex m;
+  std::vector<Ent> parked;
+  void *take(int dev, size_t bytes, size_t *cap) {
+    std::lock_guard<std::mutex> g(m);
+    size_t best = parked.size();
+    for (size_t i = 0; i < parked.size(); ++i)
+      if (parked[i].dev == dev && parked[i].bytes >= bytes && (best == parked.size() || parked[i].bytes < parked[best].bytes)) best = i;
+    if (best == parked.size()) return nullptr;
+    void *p = parked[best].p;
+    *cap = parked[best].bytes;
+    parked.erase(parked.begin() + (long)best);
+    return p;
+  }
+  void park(int dev, void *p, size_t bytes) {
+    std::lock_guard<std::mutex> g(m);
+    int mine = 0;
+    size_t smallest = parked.size();
+    for (size_t i = 0; i < parked.size(); ++i)
+      if (parked[i].dev == dev) { ++mine; if (smallest == parked.size() || parked[i].bytes < parked[smallest].bytes) smallest = i; }
+    if (mine >= 2) {                                   // keep the two largest
+      if (parked[smallest].bytes >= bytes) { (void)hipFree(p); return; }
+      (void)hipFree(parked[smallest].p);
+      parked.erase(parked.begin() + (long)smallest);
+    }
+    parked.push_back({dev, p, bytes});
+  }
+  size_t release(int dev_or_all) {
+    std::lock_guard<std::mutex> g(m);
+    size_t freed = 0;
+    for (size_t i = 0; i < parked.size();)
+      if (dev_or_all < 0 || parked[i].dev == dev_or_all) { (void)hipFree(parked[i].p); freed += parked[i].bytes; parked.erase(parked.begin() + (long)i); }
+      else ++i;
+    return freed;
+  }
+};
+BigCache &big_cache() { static BigCache *c = new BigCache; return *c; }   // never destroyed: the HIP runtime may be gone at exit
+
 // RAII device buffer
 struct DevBuf {
   void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  size_t cap = 0;
+  int dev = 0;
+  ~DevBuf() {
+    if (!p) return;
+    if (cap >= BigCache::MIN_BYTES && !getenv("DYNAALIGN_NO_BUFFER_CACHE")) big_cache().park(dev, p, cap);
+    else (void)hipFree(p);
+  }
   int alloc(size_t bytes) {
     if (bytes == 0) bytes = 16;
+    (void)hipGetDevice(&dev);
+    if (bytes >= BigCache::MIN_BYTES && (p = big_cache().take(dev, bytes, &cap)) != nullptr) return DA_OK;
     hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory && big_cache().release(dev) > 0) {   // parked buffers are the first thing to give back
+      (void)hipGetLastError();
+      e = hipMalloc(&p, bytes);
+    }
     if (e != hipSuccess) {
       p = nullptr;
       return fail(e == hipErrorOutOfMemory ? DA_ERR_NOMEM : DA_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes,
                   hipGetErrorString(e));
     }
+    cap = bytes;
     return DA_OK;
   }
   template <typename T> T *as() const { return static_cast<T *>(p); }
@@ -231,6 +288,12 @@ struct Trace {
 int64_t rows_per_block(int64_t n, size_t bytes_per_elem) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(big_cache().m);       // what is parked for reuse is as good as free
+    for (const auto &e : big_cache().parked) if (e.dev == dev) free_b += e.bytes;
+  }
   size_t budget = free_b / 2;
   if (const char *e = getenv("DYNAALIGN_BLOCK_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);
   int64_t rows = (int64_t)(budget / ((size_t)n * bytes_per_elem));
@@ -266,6 +329,8 @@ const char *da_status_message(int status) {
 }
 
 int da_abi_version(void) { return DA_ABI_VERSION; }
+
+size_t da_release_device_memory(void) { return big_cache().release(-1); }
 
 int da_device_count(void) {
   int cnt = 0;
@@ -400,6 +465,47 @@ int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues, uint8_t 
   return launch_nw_encode(d_residues, total_residues, d_codes, d_bad, static_cast<hipStream_t>(stream));
 }
 
+// similarityNW over the WHOLE pair space (symmetric mode) with byte-identical sequences collapsed first (nw_kernels.hip:
+// "duplicate sequences"): plan -> (host reads the unique count: one stream synchronisation) -> ordered DP on the unique table
+// -> index expansion to the n x n result.  Exact.  Taken when at least 15 % of the sequences are duplicates; otherwise, or
+// for what the route does not cover (sequences > 64 residues, out-of-range penalties, score output, 32-bit packed output,
+// n < 2048), the direct kernel runs.  Synchronises `stream` before returning when the route is taken (its buffers are parked
+// for the next call).  DYNAALIGN_NW_NO_DEDUP=1 switches it off.
+static int nw_full_symmetric(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t total, int64_t max_len, int mid,
+                             int gap_open, int gap_ext, int kind, void *d_out, int64_t ld, hipStream_t stream, int64_t *unique_out = nullptr) {
+  int rc;
+  if (unique_out) *unique_out = n;
+  int64_t min_n = 2048;
+  if (const char *e = getenv("DYNAALIGN_NW_DEDUP_MIN_N")) min_n = atoll(e);   // tests lower it to reach the route with tiny inputs
+  const bool eligible = n >= min_n && n <= 0x7ffffff0LL && max_len <= 64 && max_len >= 1 && (kind == DA_OUT_F64 || kind == DA_OUT_COMPACT) &&
+                        gap_open >= 0 && gap_ext >= 0 && !getenv("DYNAALIGN_NW_NO_DEDUP");
+  if (eligible) {
+    DevBuf work;
+    if ((rc = work.alloc(nw_dedup_workspace_bytes(n, total))) != DA_OK) return rc;
+    const NwDedupPlan p = nw_dedup_layout(work.p, n, total);
+    if ((rc = launch_nw_dedup_count(d_codes, d_offsets, n, p, stream)) != DA_OK) return rc;
+    int32_t M = 0, S = 0;
+    DA_HIP_TRY(hipMemcpyAsync(&M, p.pm + n, 4, hipMemcpyDeviceToHost, stream));
+    DA_HIP_TRY(hipMemcpyAsync(&S, p.ps + n, 4, hipMemcpyDeviceToHost, stream));
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+    const int64_t U = (int64_t)M + S;
+    if (unique_out) *unique_out = U;
+    if (U > 0 && U * 100 <= n * 85) {
+      if ((rc = launch_nw_dedup_build(d_codes, d_offsets, n, U, p, stream)) != DA_OK) return rc;
+      const int64_t ld_d = (U + 7) / 8 * 8;
+      DevBuf dtab;
+      if ((rc = dtab.alloc((size_t)U * (size_t)ld_d * 2)) != DA_OK) return rc;
+      if ((rc = launch_nw(p.ucodes, p.uoff, U, max_len, mid, gap_open, gap_ext, 0, U, false, DA_OUT_COMPACT, dtab.p, ld_d, nullptr, 0,
+                          stream, 0, 0, p.ufirst, p.minfirst, p.maxlast)) != DA_OK) return rc;
+      if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, kind, true, 0, d_out, ld, stream)) != DA_OK) return rc;
+      DA_HIP_TRY(hipStreamSynchronize(stream));          // work / dtab go back to the parked-buffer cache here
+      return DA_OK;
+    }
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return launch_nw(d_codes, d_offsets, n, max_len, mid, gap_open, gap_ext, 0, n, true, kind, d_out, ld, nullptr, 0, stream);
+}
+
 int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len,
               int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
               int symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score, int64_t ld_score,
@@ -411,6 +517,13 @@ int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64
     return fail(DA_ERR_BAD_ARG, "symmetric mode needs the full row range");
   if (ld < n || (d_score && ld_score < n)) return fail(DA_ERR_BAD_ARG, "leading dimension < n");
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT && kind != DA_OUT_PACK32) return fail(DA_ERR_BAD_ARG, "bad output kind");
+  if (symmetric && !d_score && kind != DA_OUT_PACK32) {   // whole pair space: duplicates are collapsed first when that pays
+    int64_t total = 0;                                     // (bytes of all sequences: last offset; one small device read)
+    DA_HIP_TRY(hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    DA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return nw_full_symmetric(d_codes, d_offsets, n, total, max_len, matrix_id, gap_open, gap_ext, kind, d_out, ld,
+                             static_cast<hipStream_t>(stream));
+  }
   return launch_nw(d_codes, d_offsets, n, max_len, matrix_id, gap_open, gap_ext, row_begin, row_end,
                    symmetric != 0, kind, d_out, ld, d_score, ld_score, static_cast<hipStream_t>(stream));
 }
@@ -694,8 +807,8 @@ static int nw_edges_core(const uint8_t *residues, const int64_t *offsets, int64_
   const int nbins = (int)((max_len << 8) | (2 * max_len)) + 1;              // matches <= max_len, length <= 2 * max_len
   if ((rc = hist.alloc((size_t)nbins * 8)) != DA_OK) return rc;
   DA_HIP_TRY(hipMemset(hist.p, 0, (size_t)nbins * 8));
-  if ((rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, 0, n, true,
-                      DA_OUT_COMPACT, cnt.p, n, nullptr, 0, nullptr)) != DA_OK) return rc;
+  if ((rc = nw_full_symmetric(codes.as<uint8_t>(), in.off.as<int64_t>(), n, total, max_len, mid, gap_open, gap_ext, DA_OUT_COMPACT,
+                              cnt.p, n, nullptr)) != DA_OK) return rc;
   if ((rc = launch_upper_histogram(cnt.as<uint16_t>(), n, n, nbins, hist.as<unsigned long long>(), nullptr)) != DA_OK) return rc;
   std::vector<double> values(nbins);
   for (int b = 0; b < nbins; ++b) {
@@ -961,8 +1074,12 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
     if ((rc = dout.alloc((size_t)std::min(blk, rows_total) * (size_t)n * sizeof(double))) != DA_OK) return rc;
     for (int64_t r0 = row_begin; r0 < row_end; r0 += blk) {
       const int64_t r1 = std::min(row_end, r0 + blk);
-      rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, r0, r1,
-                     whole, DA_OUT_F64, dout.p, n, nullptr, 0, nullptr);
+      if (whole)
+        rc = nw_full_symmetric(codes.as<uint8_t>(), in.off.as<int64_t>(), n, total, max_len, mid, gap_open, gap_ext, DA_OUT_F64,
+                               dout.p, n, nullptr);
+      else
+        rc = launch_nw(codes.as<uint8_t>(), in.off.as<int64_t>(), n, max_len, mid, gap_open, gap_ext, r0, r1,
+                       false, DA_OUT_F64, dout.p, n, nullptr, 0, nullptr);
       if (rc != DA_OK) return rc;
       if ((rc = d2h_pipelined(out_f64 + (size_t)(r0 - row_begin) * (size_t)n, dout.p,
                               (size_t)(r1 - r0) * (size_t)n * sizeof(double))) != DA_OK) return rc;

@@ -118,7 +118,23 @@ int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int3
 int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,
               int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
               bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
-              int64_t ld_score, hipStream_t stream, int shard_rank = 0, int shard_world = 0);
+              int64_t ld_score, hipStream_t stream, int shard_rank = 0, int shard_world = 0,
+              const int32_t *ord_first = nullptr, const int32_t *ord_minfirst = nullptr, const int32_t *ord_maxlast = nullptr);
+// nw_kernels.hip: collapse byte-identical sequences before the N x N sweep (exact; see the kernels' header comment)
+struct NwDedupPlan {
+  uint32_t *table; uint32_t table_size;
+  int32_t *rep, *mult, *last, *fm, *fs, *pm, *ps, *uid_of, *uidx, *ufirst, *ulast, *ulen, *minfirst, *maxlast;
+  int64_t *uoff;
+  uint8_t *ucodes;
+  size_t bytes;
+};
+NwDedupPlan nw_dedup_layout(void *work, int64_t n, int64_t total);
+size_t nw_dedup_workspace_bytes(int64_t n, int64_t total);
+int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t n, const NwDedupPlan &p, hipStream_t stream);
+int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t U, const NwDedupPlan &p, hipStream_t stream);
+// minhash_kernels.hip: out[i][j] = value(D[uidx[min(i,j)]][uidx[max(i,j)]]) for the dense symmetric n x n result
+int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
+                         void *d_out, int64_t ld, hipStream_t stream);
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
                            hipStream_t stream, int rank = 0, int world = 0);
 int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,

@@ -1209,6 +1209,87 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
   }
 }
 
+// Dense symmetric n x n result from the square table D of UNIQUE sequences (NW dedupe, nw_kernels.hip):
+//   out[i][j] = value(D[uidx[min(i,j)]][uidx[max(i,j)]])      (D is ordered: row = sequence1)
+// 64 x 64 output tiles on or above the diagonal in the banded XCD order of k_finalize_sharded, gathered through LDS so that
+// the mirrored half is written as row pieces too.  Single-copy strings are numbered in input order, so most of a row's
+// gather hits consecutive table columns; the multi-copy ones sit in the first few KiB of every table row.
+template <bool F64, bool IS_NW>
+__global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
+                                                       int n, int n_hash, void *__restrict__ out_v, int64_t ld, int TB,
+                                                       int64_t ntiles, int64_t per_xcd) {
+  constexpr int FT = 64;
+  __shared__ uint16_t t[FT][FT + 2];
+  __shared__ int32_t ur[FT], uc[FT];
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= ntiles) return;
+  const TileId tt = decode_tile(L, TB, TB, true);
+  if (!tt.valid) return;
+  const int i0 = tt.ti * FT, j0 = tt.tj * FT;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  if (threadIdx.x < 64) ur[threadIdx.x] = (i0 + (int)threadIdx.x < n) ? uidx[i0 + threadIdx.x] : 0;
+  else if (threadIdx.x < 128) uc[threadIdx.x - 64] = (j0 + (int)threadIdx.x - 64 < n) ? uidx[j0 + threadIdx.x - 64] : 0;
+  __syncthreads();
+  auto widen = [&](uint32_t v) -> double {
+    if (!IS_NW) return (double)v / (double)n_hash;
+    const uint32_t ln = v & 255u;
+    if (ln == 0) return __longlong_as_double(0xFFF8000000000000ULL);     // 0/0 as on the reference's host
+    return (double)(v >> 8) / (double)ln;                                // src/pairwiseSeqAlign.cpp:311
+  };
+  const int j = j0 + tx;
+  const int32_t cj = uc[tx];
+  for (int r = ty; r < FT; r += 4) {
+    const int i = i0 + r;
+    if (i < n && j < n && j >= i) t[r][tx] = D[(int64_t)ur[r] * ld_d + cj];
+  }
+  __syncthreads();
+  if (F64) {
+    double *out = reinterpret_cast<double *>(out_v);
+    double *o = out + (int64_t)i0 * ld + j;
+    for (int r = ty; r < FT; r += 4) {
+      const int i = i0 + r;
+      if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part
+    }
+    const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
+    double *om = out + (int64_t)j0 * ld + im;
+    for (int r = ty; r < FT; r += 4) {
+      const int jm = j0 + r;
+      if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
+    }
+  } else {
+    uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
+    uint16_t *o = out + (int64_t)i0 * ld + j;
+    for (int r = ty; r < FT; r += 4) {
+      const int i = i0 + r;
+      if (i < n && j < n && j >= i) o[(int64_t)r * ld] = t[r][tx];
+    }
+    const int im = i0 + tx;
+    uint16_t *om = out + (int64_t)j0 * ld + im;
+    for (int r = ty; r < FT; r += 4) {
+      const int jm = j0 + r;
+      if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = t[tx][r];
+    }
+  }
+}
+
+int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
+                         void *d_out, int64_t ld, hipStream_t stream) {
+  if (n <= 0) return DA_OK;
+  if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "expand: matrix too large");
+  if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "expand: bad output kind");
+  const int TB = (int)ceil_div(n, 64);
+  const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
+  if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
+  const int64_t per_xcd = ceil_div(tiles, 8);
+  const dim3 grid((unsigned)(per_xcd * 8));
+#define DA_EXP(F, W) hipLaunchKernelGGL((k_expand_unique<F, W>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd)
+  if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true); else DA_EXP(true, false); }
+  else { if (is_nw) DA_EXP(false, true); else DA_EXP(false, false); }
+#undef DA_EXP
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
                             double *d_out, int64_t ld, hipStream_t stream) {
   if (geom.n <= 0) return DA_OK;

@@ -177,7 +177,12 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
     int kind, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
-    int64_t ld_score, int64_t ntiles, int T, int shard_rank, int shard_world, int fold_q, int64_t fold_w) {
+    int64_t ld_score, int64_t ntiles, int T, int shard_rank, int shard_world, int fold_q, int64_t fold_w,
+    const int32_t *__restrict__ ord_first, const int32_t *__restrict__ ord_minfirst, const int32_t *__restrict__ ord_maxlast) {
+  // ord_first != NULL: ORDERED mode on a table of UNIQUE sequences (nw_dedup below): element (p, q) of the full square is
+  // calc(U_p, U_q) with U_p as sequence1 whatever the order of p and q, computed only where some pair i < j of the original
+  // input maps to it: first(p) < last(q) (or p == q).
+  const bool ordered = ord_first != nullptr;
   const bool f64_out = kind == DA_OUT_F64;
   __shared__ __attribute__((aligned(16))) Cell tab[CK ? 1 : 24 * 24];
   __shared__ int32_t tabk[CK ? 24 * 24 : 1];
@@ -192,7 +197,12 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   bool allow_direct = true, allow_mirror = true;
   int64_t row_shift = -row_begin;  // local output row = global row + row_shift
   int64_t col_shift = 0;           // local output column = global column + col_shift (direct stores)
-  if (symmetric) {
+  if (ordered) {
+    ti = (int)(L / T);
+    tj = (int)(L % T);
+    if (ti != tj && ord_minfirst[ti] >= ord_maxlast[tj]) return;   // no original pair i < j needs this tile
+    allow_mirror = false;
+  } else if (symmetric) {
     // row-major over the upper triangle: row t holds T - t tiles
     const double Td = (double)T;
     int64_t t = (int64_t)(Td + 0.5 - sqrt((Td + 0.5) * (Td + 0.5) - 2.0 * (double)L));
@@ -281,7 +291,8 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const int lr = wave * K3_ROWS_PER_WAVE + rr;
     const int64_t i = I0 + lr;
     if (i >= n) break;
-    if (J0 + 63 < i) continue;  // the whole wave is below the diagonal
+    if (!ordered && J0 + 63 < i) continue;  // the whole wave is below the diagonal
+    if (ordered && ti != tj && ord_first[i] >= ord_maxlast[tj]) continue;   // nothing in this row of the tile is needed
     const bool want_direct = allow_direct && i >= row_begin && i < row_end;
     const bool want_mirror_any = allow_mirror && J0 < row_end && J0 + 63 >= row_begin;
     if (!want_direct && !want_mirror_any) continue;
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     ln = p & 0xffffu;
     }
 
-    if (!jvalid || j < i) continue;
+    if (!jvalid || (!ordered && j < i)) continue;
     const bool do_direct = want_direct;
     const bool do_mirror = allow_mirror && (j != i) && j >= row_begin && j < row_end;
     if (do_mirror) my_res[rr * 64] = (mt << 16) | ln;
@@ -595,7 +606,194 @@ __global__ __launch_bounds__(K4_THREADS) void k_nw_long(
   }
 }
 
+// ---------------------------------------------------------------- duplicate sequences --
+// Byte-identical sequences have identical rows and columns in the result, so the DP only has to run on the table of
+// UNIQUE sequences and the N x N matrix is an index expansion of it (same spirit as the MinHash dictionary; exact).
+// One subtlety: calculate_similarity is not symmetric and the reference evaluates calc(seq[i], seq[j])
+// for i < j, so for two different unique strings A, B both calc(A, B) and calc(B, A) can be needed -- the first when some
+// copy of A precedes some copy of B: first(A) < last(B).  The unique table is therefore compared as an ORDERED square
+// and only where that condition can hold (k_nw_short's ordered mode); multi-copy strings are numbered before single-copy
+// ones (each group in order of first occurrence), which makes the unneeded region whole tiles.
+// h3n2-like 100k: 49 k unique strings, 3.5x fewer DP pairs; uniform peptides: nothing to collapse, the plan says so and
+// the direct kernel runs.
+constexpr uint32_t DD_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t dd_hash(const uint8_t *c, int64_t b, int32_t len) {
+  uint32_t h = 0x9747b28cu ^ (uint32_t)len;
+  for (int32_t q = 0; q < len; ++q) { h ^= c[b + q]; h *= 0x01000193u; h ^= h >> 15; }
+  h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+  return h;
+}
+__device__ __forceinline__ bool dd_same(const uint8_t *c, const int64_t *off, int64_t a, int64_t b) {
+  const int64_t ba = off[a], bb = off[b];
+  const int64_t la = off[a + 1] - ba;
+  if (la != off[b + 1] - bb) return false;
+  for (int64_t q = 0; q < la; ++q)
+    if (c[ba + q] != c[bb + q]) return false;
+  return true;
+}
+// open-addressing table of sequence indices keyed by the sequence's bytes; a slot ends up holding the SMALLEST index of
+// its string (= first occurrence).  Exact: keys are compared byte for byte, the hash only picks the start slot.
+__global__ __launch_bounds__(256) void k_dd_insert(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int32_t n,
+                                                   uint32_t *__restrict__ table, uint32_t mask) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t slot = dd_hash(codes, off[i], (int32_t)(off[i + 1] - off[i])) & mask;
+  for (;;) {
+    uint32_t o = table[slot];
+    if (o == DD_EMPTY) {
+      o = atomicCAS(&table[slot], DD_EMPTY, (uint32_t)i);
+      if (o == DD_EMPTY) return;
+    }
+    if (dd_same(codes, off, (int64_t)o, i)) { atomicMin(&table[slot], (uint32_t)i); return; }
+    slot = (slot + 1) & mask;
+  }
+}
+__global__ __launch_bounds__(256) void k_dd_lookup(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int32_t n,
+                                                   const uint32_t *__restrict__ table, uint32_t mask, int32_t *__restrict__ rep,
+                                                   int32_t *__restrict__ mult, int32_t *__restrict__ last) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t slot = dd_hash(codes, off[i], (int32_t)(off[i + 1] - off[i])) & mask;
+  for (;;) {
+    const uint32_t o = table[slot];
+    if (dd_same(codes, off, (int64_t)o, i)) {
+      rep[i] = (int32_t)o;
+      atomicAdd(&mult[o], 1);
+      atomicMax(&last[o], i);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+__global__ __launch_bounds__(256) void k_dd_flags(const int32_t *__restrict__ rep, const int32_t *__restrict__ mult, int32_t n,
+                                                  int32_t *__restrict__ fm, int32_t *__restrict__ fs) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool is_rep = rep[i] == i;
+  fm[i] = (is_rep && mult[i] > 1) ? 1 : 0;
+  fs[i] = (is_rep && mult[i] == 1) ? 1 : 0;
+}
+// exclusive prefix sum of n int32 by ONE workgroup (n is ~1e5: not worth more); out[n] = total (int64 output type OUT)
+template <typename OUT>
+__global__ __launch_bounds__(1024) void k_dd_scan(const int32_t *__restrict__ in, OUT *__restrict__ out, int32_t n) {
+  __shared__ int64_t wsum[16];
+  __shared__ int64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int32_t base = 0; base < n; base += 1024) {
+    const int32_t i = base + tid;
+    const int64_t v = i < n ? in[i] : 0;
+    int64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int64_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int64_t carry = carry_s;
+    if (i < n) out[i] = (OUT)(carry + woff + x - v);
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = (OUT)carry_s;
+}
+__global__ __launch_bounds__(256) void k_dd_assign(const int32_t *__restrict__ rep, const int32_t *__restrict__ mult,
+                                                   const int32_t *__restrict__ last, const int32_t *__restrict__ pm,
+                                                   const int32_t *__restrict__ ps, const int64_t *__restrict__ off, int32_t n,
+                                                   int32_t *__restrict__ uid_of, int32_t *__restrict__ ufirst,
+                                                   int32_t *__restrict__ ulast, int32_t *__restrict__ ulen) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || rep[i] != i) return;
+  const int32_t M = pm[n];
+  const int32_t uid = mult[i] > 1 ? pm[i] : M + ps[i];
+  uid_of[i] = uid;
+  ufirst[uid] = i;
+  ulast[uid] = last[i];
+  ulen[uid] = (int32_t)(off[i + 1] - off[i]);
+}
+__global__ __launch_bounds__(256) void k_dd_map(const int32_t *__restrict__ rep, const int32_t *__restrict__ uid_of, int32_t n,
+                                                int32_t *__restrict__ uidx) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) uidx[i] = uid_of[rep[i]];
+}
+__global__ __launch_bounds__(256) void k_dd_gather(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
+                                                   const int32_t *__restrict__ ufirst, const int64_t *__restrict__ uoff, int32_t U,
+                                                   uint8_t *__restrict__ ucodes) {
+  const int32_t u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= U) return;
+  const int64_t b = off[ufirst[u]], d = uoff[u], len = uoff[u + 1] - d;
+  for (int64_t q = 0; q < len; ++q) ucodes[d + q] = codes[b + q];
+}
+// per 64-row tile block of the unique table: smallest first occurrence, largest last occurrence
+__global__ __launch_bounds__(64) void k_dd_blocks(const int32_t *__restrict__ ufirst, const int32_t *__restrict__ ulast, int32_t U,
+                                                  int32_t *__restrict__ minfirst, int32_t *__restrict__ maxlast) {
+  const int32_t u = blockIdx.x * 64 + threadIdx.x;
+  int32_t f = u < U ? ufirst[u] : 0x7fffffff, l = u < U ? ulast[u] : -1;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    f = min(f, __shfl_xor(f, d, 64));
+    l = max(l, __shfl_xor(l, d, 64));
+  }
+  if (threadIdx.x == 0) { minfirst[blockIdx.x] = f; maxlast[blockIdx.x] = l; }
+}
+
 }  // namespace
+
+// Layout of the dedupe plan inside one workspace (all device memory; see nw_dedup_workspace_bytes)
+NwDedupPlan nw_dedup_layout(void *work, int64_t n, int64_t total) {
+  NwDedupPlan p;
+  char *w = static_cast<char *>(work);
+  auto take = [&](size_t bytes) { char *r = w; w += (bytes + 255) / 256 * 256; return r; };
+  uint32_t ts = 1024;
+  while ((int64_t)ts < 2 * n) ts <<= 1;
+  p.table_size = ts;
+  p.table = reinterpret_cast<uint32_t *>(take((size_t)ts * 4));
+  int32_t **arrs[] = {&p.rep, &p.mult, &p.last, &p.fm, &p.fs, &p.uid_of, &p.uidx, &p.ufirst, &p.ulast, &p.ulen};
+  for (auto a : arrs) *a = reinterpret_cast<int32_t *>(take((size_t)(n + 1) * 4));
+  p.pm = reinterpret_cast<int32_t *>(take((size_t)(n + 1) * 4));
+  p.ps = reinterpret_cast<int32_t *>(take((size_t)(n + 1) * 4));
+  p.uoff = reinterpret_cast<int64_t *>(take((size_t)(n + 1) * 8));
+  p.ucodes = reinterpret_cast<uint8_t *>(take((size_t)(total > 0 ? total : 1)));
+  p.minfirst = reinterpret_cast<int32_t *>(take((size_t)(n / 64 + 2) * 4));
+  p.maxlast = reinterpret_cast<int32_t *>(take((size_t)(n / 64 + 2) * 4));
+  p.bytes = (size_t)(w - static_cast<char *>(work));
+  return p;
+}
+size_t nw_dedup_workspace_bytes(int64_t n, int64_t total) { return nw_dedup_layout(nullptr, n, total).bytes + 256; }
+
+// Stage 1 (stream-ordered): everything up to the counts M (multi-copy strings) = pm[n] and S (single-copy) = ps[n].
+int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t n, const NwDedupPlan &p, hipStream_t stream) {
+  if (n <= 0 || n > 0x7ffffff0LL) return fail(DA_ERR_UNSUPPORTED, "dedupe plan: bad n");
+  const unsigned nb = (unsigned)ceil_div(n, 256);
+  DA_HIP_TRY(hipMemsetAsync(p.table, 0xff, (size_t)p.table_size * 4, stream));
+  DA_HIP_TRY(hipMemsetAsync(p.mult, 0, (size_t)n * 4, stream));
+  DA_HIP_TRY(hipMemsetAsync(p.last, 0, (size_t)n * 4, stream));
+  hipLaunchKernelGGL(k_dd_insert, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1);
+  hipLaunchKernelGGL(k_dd_lookup, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1, p.rep, p.mult, p.last);
+  hipLaunchKernelGGL(k_dd_flags, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, (int32_t)n, p.fm, p.fs);
+  hipLaunchKernelGGL(k_dd_scan<int32_t>, dim3(1), dim3(1024), 0, stream, p.fm, p.pm, (int32_t)n);
+  hipLaunchKernelGGL(k_dd_scan<int32_t>, dim3(1), dim3(1024), 0, stream, p.fs, p.ps, (int32_t)n);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+// Stage 2 (stream-ordered, U = M + S known to the host): unique ids, the unique table's codes / offsets, tile-block bounds.
+int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t U, const NwDedupPlan &p, hipStream_t stream) {
+  const unsigned nb = (unsigned)ceil_div(n, 256);
+  hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, p.last, p.pm, p.ps, d_off, (int32_t)n, p.uid_of,
+                     p.ufirst, p.ulast, p.ulen);
+  hipLaunchKernelGGL(k_dd_map, dim3(nb), dim3(256), 0, stream, p.rep, p.uid_of, (int32_t)n, p.uidx);
+  hipLaunchKernelGGL(k_dd_scan<int64_t>, dim3(1), dim3(1024), 0, stream, p.ulen, p.uoff, (int32_t)U);
+  hipLaunchKernelGGL(k_dd_gather, dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, stream, d_codes, d_off, p.ufirst, p.uoff, (int32_t)U, p.ucodes);
+  hipLaunchKernelGGL(k_dd_blocks, dim3((unsigned)ceil_div(U, 64)), dim3(64), 0, stream, p.ufirst, p.ulast, (int32_t)U, p.minfirst, p.maxlast);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
 
 int launch_nw_encode(const uint8_t *d_res, int64_t total, uint8_t *d_codes, int32_t *d_bad,
                      hipStream_t stream) {
@@ -618,7 +816,8 @@ int matrix_count_host() { return DA_NUM_MATRICES; }
 int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t max_len,
               int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
               bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
-              int64_t ld_score, hipStream_t stream, int shard_rank, int shard_world) {
+              int64_t ld_score, hipStream_t stream, int shard_rank, int shard_world,
+              const int32_t *ord_first, const int32_t *ord_minfirst, const int32_t *ord_maxlast) {
   if (n <= 0 || row_end <= row_begin) return DA_OK;
   const signed char *tab = matrix_table_host(matrix_id);
   if (!tab) return fail(DA_ERR_BAD_ARG, "matrix id %d out of range", matrix_id);
@@ -635,6 +834,7 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   // 33..64: the same kernel with the combined key only (the int32 form would need > 256 VGPRs);
   // otherwise the wavefront-per-pair anti-diagonal kernel
   if (max_len > 64 || (max_len > 32 && !ck)) {
+    if (ord_first) return fail(DA_ERR_UNSUPPORTED, "ordered (deduplicated) NW is built for the lane-per-pair kernel (<= 64 residues)");
     if (shard_world > 0) return fail(DA_ERR_UNSUPPORTED, "row-sharded NW is built for sequences up to 64 residues (default-range gap penalties)");
     ScoreTable st4;
     for (int e = 0; e < 576; ++e) st4.s[e] = tab[e];
@@ -668,7 +868,8 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   const int fold_q = shard_world > 0 ? sg.Q : 0;
   const int64_t fold_w = sg.W;
   int64_t ntiles;
-  if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
+  if (ord_first) ntiles = (int64_t)T * T;
+  else if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
   else if (shard_world > 0) ntiles = ceil_div(T, shard_world) * (int64_t)T;
   else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
   if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
@@ -676,10 +877,10 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
 #define DA_K3(NM)                                                                                   \
   if (ck) hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w);                   \
+                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast); \
   else hipLaunchKernelGGL((k_nw_short<NM, false>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w)
+                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast)
   if (max_len <= 8) DA_K3(8);
   else if (max_len <= 12) DA_K3(12);
   else if (max_len <= 16) DA_K3(16);
@@ -690,7 +891,7 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
 #define DA_K3CK(NM)                                                                                    \
   hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
                      (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w)
+                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast)
     if (max_len <= 48) DA_K3CK(48); else DA_K3CK(64);
 #undef DA_K3CK
   }

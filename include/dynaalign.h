@@ -72,6 +72,9 @@ const char *da_last_error(void);
 const char *da_status_message(int status); /* static text for a code ("" if none) */
 int da_abi_version(void);
 int da_device_count(void); /* 0 when no HIP device is usable */
+/* The host-pointer entry points park their large device buffers (>= 256 MiB, at most two per device: the 80 GB
+ * result buffer costs seconds to allocate) for the next call; this returns them to the driver.  Returns the bytes freed. */
+size_t da_release_device_memory(void);
 
 /* ---- HashFamily (reference src/minHash.cpp:67-89) ------------------------ */
 
