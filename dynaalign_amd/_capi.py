@@ -44,6 +44,7 @@ SIGNATURES = {
     "da_mh_planes_workspace_bytes": (_sz, [_i64, _i32]),
     "da_dev_mh_planes": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _sz, _vp, _i64, _vp, _vp]),
     "da_dev_mh_compare": (_i32, [_vp, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "da_nw_last_route": (_i32, [_vp, _vp, _vp, _vp]),
     "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "da_similarity_mh_edges": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, C.c_double, _vp, _vp, _i64, _vp, _vp, _vp]),

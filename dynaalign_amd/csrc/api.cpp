@@ -471,10 +471,22 @@ int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues, uint8_t 
 // for what the route does not cover (sequences > 64 residues, out-of-range penalties, score output, 32-bit packed output,
 // n < 2048), the direct kernel runs.  Synchronises `stream` before returning when the route is taken (its buffers are parked
 // for the next call).  DYNAALIGN_NW_NO_DEDUP=1 switches it off.
+// what the last whole-matrix NW call of this thread did (da_nw_last_route: bench.py's roofline object needs the DP
+// kernel's own duration, and the call is one C entry point)
+struct NwRoute { int64_t n = 0, unique = 0; int taken = 0; float plan_ms = 0, dp_ms = 0, expand_ms = 0; };
+static NwRoute &nw_route() { static thread_local NwRoute r; return r; }
+
 static int nw_full_symmetric(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t total, int64_t max_len, int mid,
                              int gap_open, int gap_ext, int kind, void *d_out, int64_t ld, hipStream_t stream, int64_t *unique_out = nullptr) {
   int rc;
   if (unique_out) *unique_out = n;
+  NwRoute &route = nw_route();
+  route = NwRoute();
+  route.n = route.unique = n;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 4; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } guard{ev};
+  for (auto &e : ev) DA_HIP_TRY(hipEventCreate(&e));
+  DA_HIP_TRY(hipEventRecord(ev[0], stream));
   int64_t min_n = 2048;
   if (const char *e = getenv("DYNAALIGN_NW_DEDUP_MIN_N")) min_n = atoll(e);   // tests lower it to reach the route with tiny inputs
   const bool eligible = n >= min_n && n <= 0x7ffffff0LL && max_len <= 64 && max_len >= 1 && (kind == DA_OUT_F64 || kind == DA_OUT_COMPACT) &&
@@ -490,20 +502,43 @@ static int nw_full_symmetric(const uint8_t *d_codes, const int64_t *d_offsets, i
     DA_HIP_TRY(hipStreamSynchronize(stream));
     const int64_t U = (int64_t)M + S;
     if (unique_out) *unique_out = U;
+    route.unique = U;
     if (U > 0 && U * 100 <= n * 85) {
       if ((rc = launch_nw_dedup_build(d_codes, d_offsets, n, U, p, stream)) != DA_OK) return rc;
       const int64_t ld_d = (U + 7) / 8 * 8;
       DevBuf dtab;
       if ((rc = dtab.alloc((size_t)U * (size_t)ld_d * 2)) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(ev[1], stream));
       if ((rc = launch_nw(p.ucodes, p.uoff, U, max_len, mid, gap_open, gap_ext, 0, U, false, DA_OUT_COMPACT, dtab.p, ld_d, nullptr, 0,
                           stream, 0, 0, p.ufirst, p.minfirst, p.maxlast)) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(ev[2], stream));
       if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, kind, true, 0, d_out, ld, stream)) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(ev[3], stream));
       DA_HIP_TRY(hipStreamSynchronize(stream));          // work / dtab go back to the parked-buffer cache here
+      route.taken = 1;
+      (void)hipEventElapsedTime(&route.plan_ms, ev[0], ev[1]);
+      (void)hipEventElapsedTime(&route.dp_ms, ev[1], ev[2]);
+      (void)hipEventElapsedTime(&route.expand_ms, ev[2], ev[3]);
       return DA_OK;
     }
     DA_HIP_TRY(hipStreamSynchronize(stream));
   }
-  return launch_nw(d_codes, d_offsets, n, max_len, mid, gap_open, gap_ext, 0, n, true, kind, d_out, ld, nullptr, 0, stream);
+  DA_HIP_TRY(hipEventRecord(ev[1], stream));
+  if ((rc = launch_nw(d_codes, d_offsets, n, max_len, mid, gap_open, gap_ext, 0, n, true, kind, d_out, ld, nullptr, 0, stream)) != DA_OK) return rc;
+  DA_HIP_TRY(hipEventRecord(ev[2], stream));
+  DA_HIP_TRY(hipEventSynchronize(ev[2]));                // (the direct route used to be asynchronous; the timing costs that)
+  (void)hipEventElapsedTime(&route.plan_ms, ev[0], ev[1]);
+  (void)hipEventElapsedTime(&route.dp_ms, ev[1], ev[2]);
+  return DA_OK;
+}
+
+int da_nw_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, double *ms3_out) {
+  const NwRoute &r = nw_route();
+  if (n_out) *n_out = r.n;
+  if (unique_out) *unique_out = r.unique;
+  if (dedup_taken_out) *dedup_taken_out = r.taken;
+  if (ms3_out) { ms3_out[0] = r.plan_ms; ms3_out[1] = r.dp_ms; ms3_out[2] = r.expand_ms; }
+  return DA_OK;
 }
 
 int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64_t max_len,
@@ -539,14 +574,14 @@ int da_dev_widen(const uint16_t *d_in, double *d_out, int64_t count, int is_nw, 
 }
 
 // ---- row-sharding over `world` ranks: rank p owns tile rows p, p+world, ... (cyclic, so
-// the upper-triangular work is balanced); tile = 128 rows for MH, 64 for NW.
+// the upper-triangular work is balanced); the unit is 128 rows for both kinds.
 int64_t da_shard_rows(int64_t n, int world, int is_nw) {
   if (n <= 0 || world <= 0) return 0;
-  return shard_geom(n, world, is_nw ? 64 : 128).rows;
+  return shard_geom(n, world, 128).rows;
 }
 int64_t da_shard_ld(int64_t n, int world, int is_nw) {
   if (n <= 0 || world <= 0) return 0;
-  return shard_geom(n, world, is_nw ? 64 : 128).W;
+  return shard_geom(n, world, 128).W;
 }
 
 int da_dev_mh_compare_shard(const uint32_t *d_planes, int plane_bits, int64_t n, int n_hash, int rank,
@@ -599,7 +634,7 @@ int da_dev_nw_shard(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n,
   if (n <= 0) return DA_OK;
   if (!d_codes || !d_offsets || !d_local || world <= 0 || rank < 0 || rank >= world)
     return fail(DA_ERR_BAD_ARG, "bad shard arguments");
-  if (ld < shard_geom(n, world, 64).W) return fail(DA_ERR_BAD_ARG, "ld < da_shard_ld");
+  if (ld < shard_geom(n, world, 128).W) return fail(DA_ERR_BAD_ARG, "ld < da_shard_ld");
   return launch_nw(d_codes, d_offsets, n, max_len, matrix_id, gap_open, gap_ext, 0, n, false, DA_OUT_COMPACT, d_local, ld,
                    nullptr, 0, static_cast<hipStream_t>(stream), rank, world);
 }
@@ -608,7 +643,7 @@ int da_dev_finalize_shards(const uint16_t *d_gathered, int64_t ld_g, int64_t n, 
                            double *d_out, int64_t ld_out, void *stream) {
   if (n <= 0) return DA_OK;
   if (!d_gathered || !d_out || world <= 0 || ld_out < n) return fail(DA_ERR_BAD_ARG, "bad finalize arguments");
-  const ShardGeom sg = shard_geom(n, world, is_nw ? 64 : 128);
+  const ShardGeom sg = shard_geom(n, world, 128);
   if (ld_g < sg.W) return fail(DA_ERR_BAD_ARG, "ld_g < da_shard_ld");
   return launch_finalize_sharded(d_gathered, ld_g, sg, is_nw != 0, n_hash, d_out, ld_out, static_cast<hipStream_t>(stream));
 }
@@ -949,14 +984,56 @@ int da_minhash_signatures(const uint8_t *residues, const int64_t *offsets, int64
   return DA_OK;
 }
 
+// similarityMH with more hash functions than the compare kernels' 16-bit counters hold (n_hash > 65535; the reference has
+// no limit, src/minHash.cpp:129-131 only asks for > 0): chunks of <= 65504 hash functions go through K1 / K1b / K2 (uint16
+// counts) one after the other, the counts are summed in 32 bits on the device and divided by n_hash once.  Needs the whole
+// n x n count matrix resident (4 + 2 + 8 bytes per pair).
+static int mh_host_chunked(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash, const uint32_t *seeds,
+                           double *out) {
+  constexpr int CHUNK = 65504;                              // a multiple of 32 below 65536
+  int64_t total, max_len;
+  int rc;
+  if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
+  if ((rc = require_device()) != DA_OK) return rc;
+  if (rows_per_block(n, 4 + 2 + 8) < n)
+    return fail(DA_ERR_UNSUPPORTED, "n_hash = %d (> 65535) needs the %lld x %lld count matrix resident in HBM (14 bytes per pair)", n_hash,
+                (long long)n, (long long)n);
+  DeviceInput in;
+  if ((rc = in.upload(residues, offsets, n, total, seeds, n_hash)) != DA_OK) return rc;
+  const int64_t lds = sig_ld_for(CHUNK);
+  DevBuf sig, planes, work, acc, cnt, dout;
+  const size_t wb = mh_planes_workspace_bytes(n, CHUNK);
+  if ((rc = sig.alloc((size_t)n * lds * 4)) != DA_OK) return rc;
+  if ((rc = planes.alloc((size_t)mh_planes_words(n, CHUNK) * 4)) != DA_OK) return rc;
+  if ((rc = work.alloc(wb)) != DA_OK) return rc;
+  if ((rc = acc.alloc((size_t)n * (size_t)n * 4)) != DA_OK) return rc;
+  if ((rc = cnt.alloc((size_t)n * (size_t)n * 2)) != DA_OK) return rc;
+  for (int h0 = 0; h0 < n_hash; h0 += CHUNK) {
+    const int nh = std::min(CHUNK, n_hash - h0);
+    if ((rc = launch_minhash_signatures(in.res.as<uint8_t>(), in.off.as<int64_t>(), n, k, nh, in.seeds.as<uint32_t>() + h0,
+                                        sig.as<uint32_t>(), lds, nullptr)) != DA_OK) return rc;
+    int bits = 32;
+    if ((rc = build_planes(sig.as<uint32_t>(), lds, n, nh, 0, work.p, wb, planes.as<uint32_t>(), &bits, nullptr)) != DA_OK) return rc;
+    if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, nh, 0, n, true, DA_OUT_COMPACT, cnt.p, n, nullptr, bits)) != DA_OK) return rc;
+    if ((rc = launch_acc_counts(acc.as<uint32_t>(), cnt.as<uint16_t>(), n * n, h0 == 0, nullptr)) != DA_OK) return rc;
+  }
+  if ((rc = dout.alloc((size_t)n * (size_t)n * 8)) != DA_OK) return rc;
+  if ((rc = launch_counts32_to_f64(acc.as<uint32_t>(), dout.as<double>(), n * n, n_hash, nullptr)) != DA_OK) return rc;
+  rc = d2h_pipelined(out, dout.p, (size_t)n * (size_t)n * 8);
+  DA_HIP_TRY(hipDeviceSynchronize());
+  return rc;
+}
+
 static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64_t n, int k, int n_hash,
                           const uint32_t *seeds, int64_t row_begin, int64_t row_end, int kind, void *out) {
   int rc = validate_mh(n, k, n_hash);
   if (rc != DA_OK) return rc;
   if (!residues || !seeds || !out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
   if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(DA_ERR_BAD_ARG, "bad row range");
+  if (n_hash > 65535 && kind == DA_OUT_F64 && row_begin == 0 && row_end == n)
+    return mh_host_chunked(residues, offsets, n, k, n_hash, seeds, static_cast<double *>(out));
   if (n_hash > 65535)
-    return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
+    return fail(DA_ERR_UNSUPPORTED, "uint16 match counts cannot hold n_hash = %d (> 65535); da_similarity_mh handles it", n_hash);
   int64_t total, max_len;
   if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
   if ((rc = require_device()) != DA_OK) return rc;
@@ -1336,11 +1413,14 @@ int da_similarity_mh_opts(const uint8_t *residues, const int64_t *offsets, int64
   int rc = validate_mh(n, k, n_hash);
   if (rc != DA_OK) return rc;
   if (!residues || !seeds || !out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
-  if (n_hash > 65535) return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
   int64_t total, max_len;
   if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
   Multi m;
   if ((rc = parse_opts(opts, m)) != DA_OK) return rc;
+  if (n_hash > 65535 && !(m.P == 1 && m.exchange == DA_EXCHANGE_ROWS)) {
+    destroy_comms(m);
+    return fail(DA_ERR_UNSUPPORTED, "n_hash = %d (> 65535) runs on one device only (16-bit counters in the sharded kernels)", n_hash);
+  }
   if (m.P == 1 && m.exchange == DA_EXCHANGE_ROWS)      // one device, nothing to split: the symmetric single-device path
     return run_ranks(m, opts, [&](int) -> int {
       return mh_host_common(residues, offsets, n, k, n_hash, seeds, 0, n, DA_OUT_F64, out);
@@ -1442,7 +1522,7 @@ int da_similarity_nw_opts(const uint8_t *residues, const int64_t *offsets, int64
     return run_ranks(m, opts, [&](int) -> int {
       return nw_host_common(residues, offsets, n, matrix_name, gap_open, gap_ext, 0, n, out, nullptr, nullptr, nullptr);
     });
-  const ShardGeom sg = shard_geom(n, m.P, 64);
+  const ShardGeom sg = shard_geom(n, m.P, 128);
   const size_t blk_bytes = (size_t)sg.rows * (size_t)sg.W * 2;
   return run_ranks(m, opts, [&](int p) -> int {
     int rc = DA_OK;

@@ -141,6 +141,8 @@ int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8
                          bool include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
                          unsigned long long *d_count, hipStream_t stream, int rank = 0, int world = 0);
 int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream);
+int launch_acc_counts(uint32_t *d_acc, const uint16_t *d_cnt, int64_t count, bool first, hipStream_t stream);
+int launch_counts32_to_f64(const uint32_t *d_acc, double *d_out, int64_t count, int n_hash, hipStream_t stream);
 int launch_widen(const uint16_t *d_in, double *d_out, int64_t count, bool is_nw, int n_hash,
                  hipStream_t stream);
 

@@ -1033,7 +1033,33 @@ __global__ __launch_bounds__(256) void k_widen(const uint16_t *__restrict__ in, 
   }
 }
 
+// n_hash > 65535 (host-pointer path only): the compare kernels count in 16 bits, so the hash functions are processed in
+// chunks and the chunk counts summed in 32 bits; the divide happens once, on the total (src/minHash.cpp:174)
+__global__ __launch_bounds__(256) void k_acc_counts(uint32_t *__restrict__ acc, const uint16_t *__restrict__ cnt, int64_t count, int first) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    acc[i] = (first ? 0u : acc[i]) + cnt[i];
+}
+__global__ __launch_bounds__(256) void k_counts32_to_f64(const uint32_t *__restrict__ acc, double *__restrict__ out, int64_t count, int n_hash) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    out[i] = (double)acc[i] / (double)n_hash;
+}
+
 }  // namespace
+
+int launch_acc_counts(uint32_t *d_acc, const uint16_t *d_cnt, int64_t count, bool first, hipStream_t stream) {
+  if (count <= 0) return DA_OK;
+  hipLaunchKernelGGL(k_acc_counts, dim3(256 * 16), dim3(256), 0, stream, d_acc, d_cnt, count, first ? 1 : 0);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+int launch_counts32_to_f64(const uint32_t *d_acc, double *d_out, int64_t count, int n_hash, hipStream_t stream) {
+  if (count <= 0) return DA_OK;
+  hipLaunchKernelGGL(k_counts32_to_f64, dim3(256 * 16), dim3(256), 0, stream, d_acc, d_out, count, n_hash);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
 
 #ifdef DA_K2_TIMING
 extern "C" int da_debug_set_k2_timing(unsigned long long *d_buf) {

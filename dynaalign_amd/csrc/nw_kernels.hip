@@ -214,18 +214,22 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     ti = (int)t;
     tj = (int)(t + (L - start(t)));
   } else if (shard_world > 0) {
-    // cyclic shard of one rank: local tile row q is global tile row q*world + rank; only
+    // cyclic shard of one rank: local unit u is global 128-row unit u*world + rank; only
     // upper tiles, direct store into local rows q*64 + [0,64) (the mirror is filled after
     // the all-gather by k_finalize_sharded)
-    const int q = (int)(L / T);
-    ti = q * shard_world + shard_rank;
+    // ranks are dealt 128-row UNITS (two of this kernel's 64-row tile rows), the same unit and folded layout as the
+    // MinHash shards -- so the histogram / edge-extraction kernels (graph_kernels.hip) read both kinds of block
+    const int q64 = (int)(L / T);                         // local 64-row tile row
+    const int u = q64 >> 1;                               // local unit
+    const int gu = u * shard_world + shard_rank;          // global unit
+    ti = 2 * gu + (q64 & 1);
     tj = (int)(L % T);
     if (ti >= T || tj < ti) return;
     allow_mirror = false;
-    {  // folded shard layout (ShardGeom): tile rows q and Q-1-q share a stored row
-      const bool front = q <= fold_q - 1 - q;
-      row_shift = (int64_t)(front ? q : fold_q - 1 - q) * K3_TILE - (int64_t)ti * K3_TILE;
-      col_shift = front ? -(int64_t)ti * K3_TILE : fold_w - n;
+    {  // folded shard layout (ShardGeom, tile = 128): units u and Q-1-u share a stored unit row
+      const bool front = u <= fold_q - 1 - u;
+      row_shift = (int64_t)(front ? u : fold_q - 1 - u) * 128 + (int64_t)(q64 & 1) * K3_TILE - (int64_t)ti * K3_TILE;
+      col_shift = front ? -(int64_t)gu * 128 : fold_w - n;
     }
   } else {
     // row-block request: tile row rt (inside the block) x every tile column tc.
@@ -864,13 +868,13 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   ScoreTable st;
   for (int e = 0; e < 576; ++e) st.s[e] = tab[e];
   const int T = (int)ceil_div(n, K3_TILE);
-  const ShardGeom sg = shard_geom(n, shard_world > 0 ? shard_world : 1, K3_TILE);
+  const ShardGeom sg = shard_geom(n, shard_world > 0 ? shard_world : 1, 128);
   const int fold_q = shard_world > 0 ? sg.Q : 0;
   const int64_t fold_w = sg.W;
   int64_t ntiles;
   if (ord_first) ntiles = (int64_t)T * T;
   else if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
-  else if (shard_world > 0) ntiles = ceil_div(T, shard_world) * (int64_t)T;
+  else if (shard_world > 0) ntiles = 2 * (int64_t)sg.Q * T;          // 2 tile rows per 128-row unit, Q units per rank
   else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
   if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)ntiles), block(K3_THREADS);

@@ -204,3 +204,11 @@ def extract_edges(compact, n, keep, capacity, include_diagonal=True):
                                                   keep_t.numel(), 1 if include_diagonal else 0, ei.data_ptr(),
                                                   ej.data_ptr(), ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream()))
     return ei, ej, ev, cnt
+
+
+def nw_last_route():
+    """what this thread's last whole-matrix NW call did: dict(n, unique, dedup, plan_ms, dp_ms, expand_ms)"""
+    n, u, t = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+    ms = (ctypes.c_double * 3)()
+    _capi.check(_capi.load().da_nw_last_route(ctypes.addressof(n), ctypes.addressof(u), ctypes.addressof(t), ctypes.addressof(ms)))
+    return {"n": n.value, "unique": u.value, "dedup": bool(t.value), "plan_ms": ms[0], "dp_ms": ms[1], "expand_ms": ms[2]}

@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 from . import _capi
 
-MH_TILE, NW_TILE = 128, 64
+MH_TILE, NW_TILE = 128, 128    # rows per cyclic unit; the NW kernel's own tile is 64 x 64, two tile rows per unit
 
 
 class Plan:
@@ -233,17 +233,20 @@ def shard_extract_edges(plan, local, keep, capacity):
     return ei, ej, ev, cnt
 
 
-def edges_from_histograms(plan, local_hist, n_hash, thresh_p, reduce_fn, extract_fn):
+def edges_from_histograms(plan, local_hist, n_hash, thresh_p, reduce_fn, extract_fn, values=None):
     """Backend-independent part: reduce the histograms, derive threshold + keep mask, extract local edges.
-    local_hist: int64 tensor [n_hash+1] (strict upper triangle of this rank's pairs);
-    reduce_fn(tensor) sums it over ranks in place; extract_fn(keep, capacity) -> (i, j, v, count)."""
+    local_hist: int64 tensor [nbins] (strict upper triangle of this rank's pairs);
+    reduce_fn(tensor) sums it over ranks in place; extract_fn(keep, capacity) -> (i, j, v, count).
+    values[b] = the similarity bin b stands for (default: MinHash, b / n_hash); bins need not be in value order."""
     import numpy as np
     from .similarity import quantile_type7
     total = local_hist.clone()
     reduce_fn(total)
-    values = np.arange(n_hash + 1, dtype=np.float64) / n_hash          # src/minHash.cpp:174
-    thr = quantile_type7(total.cpu().numpy().astype(np.uint64), values, thresh_p)
-    keep = (~(values < thr)) & (np.arange(n_hash + 1) != 0)            # S[S < thr] <- 0; zero weight = no edge
+    if values is None:
+        values = np.arange(n_hash + 1, dtype=np.float64) / n_hash      # src/minHash.cpp:174
+    order = np.argsort(values, kind="stable")                          # order statistics need ascending VALUES
+    thr = quantile_type7(total.cpu().numpy().astype(np.uint64)[order], values[order], thresh_p)
+    keep = (~(values < thr)) & (values != 0.0)                         # S[S < thr] <- 0; zero weight = no edge
     mine = local_hist.cpu().numpy()
     capacity = int(mine[keep].sum()) + len(plan.my_rows())             # + this rank's diagonal entries (1.0)
     ei, ej, ev, cnt = extract_fn(keep, capacity)
@@ -264,3 +267,34 @@ def mh_edges_sharded(plan, work, planes, n_hash, thresh_p, group=None):
     thr, ei, ej, ev, cnt, cap = edges_from_histograms(plan, hist, n_hash, thresh_p, reduce_fn,
                                                       lambda keep, c: shard_extract_edges(plan, work.local, keep, c))
     return thr, ei, ej, ev, cnt
+
+
+def nw_code_values(max_len):
+    """similarity a uint16 NW code (matches << 8 | length) stands for: matches / length (src/pairwiseSeqAlign.cpp:311)"""
+    import numpy as np
+    nbins = ((int(max_len) << 8) | (2 * int(max_len))) + 1
+    b = np.arange(nbins)
+    ln = (b & 255).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        v = np.where(ln > 0, (b >> 8) / ln, 0.0)
+    return v
+
+
+def nw_edges_sharded(plan, work, ds, thresh_p, matrix_name="BLOSUM62", gap_open=10, gap_ext=4, group=None):
+    """similarityNW + clusterbreak's threshold step without any N x N exchange (the NW twin of mh_edges_sharded): this
+    rank's shard of alignment codes -> local histogram of the codes -> ONE all-reduce -> exact type-7 quantile of the
+    ratios -> this rank's surviving edges.  Sequences of 1..64 residues (an empty one makes NaN similarities, on which R's
+    quantile() stops).  Returns (threshold, i, j, codes, n_local_edges, values) -- weight of an edge = values[code]."""
+    if ds.max_len > 64 or int((ds.offsets_host[1:] == ds.offsets_host[:-1]).sum()) > 0:
+        raise _capi.DynaAlignError(_capi.DA_ERR_UNSUPPORTED, "sharded NW edges: sequences of 1..64 residues")
+    nw_local_block(plan, work, ds, matrix_name, gap_open, gap_ext)
+    values = nw_code_values(ds.max_len)
+    hist = shard_histogram(plan, work.local, len(values))
+
+    def reduce_fn(t):
+        if plan.world > 1:
+            dist.all_reduce(t, group=group)
+
+    thr, ei, ej, ev, cnt, cap = edges_from_histograms(plan, hist, 0, thresh_p, reduce_fn,
+                                                      lambda keep, c: shard_extract_edges(plan, work.local, keep, c), values=values)
+    return thr, ei, ej, ev, cnt, values

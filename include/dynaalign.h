@@ -221,9 +221,18 @@ int da_dev_nw(const uint8_t *d_codes, const int64_t *d_offsets, int64_t n, int64
               int kind, void *d_out, int64_t ld, int32_t *d_score, int64_t ld_score,
               void *stream);
 
+/* With symmetric != 0, kind F64 / COMPACT and no score output, da_dev_nw (and da_similarity_nw[_edges]) first collapse
+ * byte-identical sequences: the DP runs on the table of unique strings -- as an ORDERED square, calculate_similarity is
+ * not symmetric (src/pairwiseSeqAlign.cpp:340-346 evaluates calc(seq[i], seq[j]), i < j) -- and the n x n result is an index
+ * expansion of it.  Exact; taken when >= 15 % of the sequences are duplicates, n >= 2048, sequences <= 64 residues,
+ * penalties >= 0; synchronises the stream.  DYNAALIGN_NW_NO_DEDUP=1 disables it.  da_nw_last_route reports what the calling
+ * thread's last such call did: n, unique strings, whether the route was taken, and {plan, DP kernel, expansion} times in ms
+ * (direct route: {0, DP kernel, 0}).  Any pointer may be NULL. */
+int da_nw_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, double *ms3_out);
+
 /* ---- row-sharding of the pair space over the GPUs of a node ---
  * Rank p of `world` owns the tile rows p, p+world, p+2*world, ... of the pair
- * space (tile = 128 rows for MH, 64 for NW; cyclic so the upper-triangular work
+ * space (tile = 128 rows for both kinds; cyclic so the upper-triangular work
  * is balanced) and computes only the tiles on or right of the diagonal.  Its
  * result is a compact uint16 block of da_shard_rows() rows x da_shard_ld()
  * columns in a FOLDED layout: local tile rows q and Q-1-q share one stored tile

@@ -61,6 +61,40 @@ def test_signatures_and_counts_match_golden(da, golden, k, n_hash):
     assert_same_f64(M, golden["mh_cnt_k%d_h%d" % (k, n_hash)].astype(np.float64) / n_hash)
 
 
+def test_more_hash_functions_than_16_bit_counters(da):
+    """n_hash > 65535: the reference has no upper limit (src/minHash.cpp:129-131); the host entry point processes the hash
+    functions in chunks of 65504 and sums the counts in 32 bits.  n = 300 has interior tiles; duplicates give count == n_hash."""
+    from dynaalign_amd import synth
+    n, n_hash = 300, 70000
+    seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+    seqs[200:220] = seqs[0:20]
+    seeds = da.hash_family_seeds(5, n_hash)
+    rc, want = O.similarity_mh(seqs, 4, n_hash, seeds)
+    assert rc == 0 and want[0, 200] == 1.0
+    assert_same_f64(da.similarityMH(seqs, 4, n_hash, seed=5), want)
+    assert_same_f64(da.similarityMH(seqs, 4, n_hash, seed=5, devices=[0]), want)
+    with pytest.raises(da.DynaAlignError, match="one device only"):
+        da.similarityMH(seqs, 4, n_hash, seed=5, devices=[0, 0])
+    with pytest.raises(da.DynaAlignError, match="uint16 match counts cannot hold"):
+        da.mh_counts(seqs, 4, n_hash, seed=5)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 9])
+def test_bytes_above_0x7f_are_hashed_as_they_are(da, k):
+    """the reference hashes the raw bytes of the CHARSXP: 4-byte blocks through a uint32 read, the tail through uint8
+    (src/minHash.cpp:32,43) -- no sign extension, no re-encoding.  Latin-1 strings with bytes 0x80..0xFF (and control bytes)
+    through the packed-byte boundary: signatures, counts and the matrix against the oracle."""
+    rng = np.random.RandomState(k)
+    seqs = ["".join(chr(int(b)) for b in rng.randint(1, 256, int(rng.randint(0, 30)))) for _ in range(200)]
+    seqs += [chr(255) * 12, "".join(chr(c) for c in (128, 129, 130, 131, 132)), chr(255) * 12, "A" + chr(233) + chr(232) + "B" + chr(252) + "C"]
+    seeds = da.hash_family_seeds(777, 100)
+    want_sig = O.signatures(seqs, k, 100, seeds)
+    assert np.array_equal(da.minhash_signatures(seqs, k, 100, seed=777), want_sig)
+    rc, want = O.similarity_mh(seqs, k, 100, seeds)
+    assert rc == 0
+    assert_same_f64(da.similarityMH(seqs, k, 100, seed=777), want)
+
+
 @pytest.mark.parametrize("n,k,n_hash", [(1, 4, 50), (2, 4, 500), (127, 4, 500), (128, 2, 50), (129, 4, 33),
                                         (300, 3, 7), (641, 2, 50), (1000, 4, 500), (1025, 6, 129)])
 def test_similarity_mh_matches_oracle(da, evp, n, k, n_hash):

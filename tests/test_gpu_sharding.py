@@ -169,3 +169,52 @@ def test_mh_packed_exchange_virtual_ranks(da, world, n, n_hash):
         out2 = torch.empty_like(out)
         sharding.mh_sharded_step_packed(plan, work, planes, n_hash, out2)
         assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("n,lens", [(700, (20, 20)), (333, (1, 40))])
+def test_nw_edges_sharded_virtual_ranks(da, world, n, lens):
+    """the NW twin of the sharded MinHash edge list: the ranks' code histograms sum to the dense histogram, the union of
+    their edge lists is the dense threshold step on the oracle's similarityNW matrix (quantile over RATIOS: codes such as
+    1/2 and 2/4 are different bins of equal value)"""
+    from dynaalign_amd import device, sharding, synth
+    from test_threshold_edges import reference_edges
+    rng = np.random.RandomState(n + world)
+    if lens[0] == lens[1]:
+        res, off = synth.h3n2_like(n, lens[0])
+        seqs = synth.to_strings(res, off)
+    else:
+        alpha = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
+        seqs = ["".join(map(chr, alpha[rng.randint(0, 20, rng.randint(lens[0], lens[1] + 1))])) for _ in range(n)]
+        res, off = da.pack_sequences(seqs)
+    ds = device.DeviceSequences(res, off)
+    assert int(device.nw_encode(ds).item()) == 0
+    rc, M, _ = O.similarity_nw(seqs)
+    assert rc == 0
+    thr_w, iw, jw, ww = reference_edges(M, 0.8)
+    plans = [sharding.Plan(n, r, world, sharding.NW_TILE) for r in range(world)]
+    works = [sharding.Workspace(pl) for pl in plans]
+    values = sharding.nw_code_values(ds.max_len)
+    hists = []
+    for pl, w in zip(plans, works):
+        w.local.fill_(0x7FFF)
+        sharding.nw_local_block(pl, w, ds)
+        hists.append(sharding.shard_histogram(pl, w.local, len(values)))
+    total = torch.stack(hists).sum(0)
+    assert int(total.sum().item()) == n * (n - 1) // 2
+    edges = {}
+    for pl, w, h in zip(plans, works, hists):
+        thr, ei, ej, ev, c, cap = sharding.edges_from_histograms(
+            pl, h, 0, 0.8, lambda t: t.copy_(total),
+            lambda keep, capacity: sharding.shard_extract_edges(pl, w.local, keep, capacity), values=values)
+        m = int(c.item())
+        assert m == cap and thr == thr_w
+        for a, b, v in zip(ei[:m].cpu().numpy(), ej[:m].cpu().numpy(), ev[:m].cpu().numpy().view(np.uint16)):
+            key = (int(a), int(b))
+            assert key not in edges and pl.owner(int(a)) == pl.rank
+            edges[key] = values[v]
+    assert sorted(edges) == list(zip(iw.tolist(), jw.tolist()))
+    assert [edges[k] for k in sorted(edges)] == ww.tolist()
+    if world == 1:                                             # the one-call form agrees
+        thr, ei, ej, ev, c, vals = sharding.nw_edges_sharded(plans[0], works[0], ds, 0.8)
+        assert thr == thr_w and int(c.item()) == len(iw)
