@@ -136,9 +136,10 @@ def test_mh_extreme_parameters(da):
         assert np.array_equal(da.mh_counts(seqs, k, n_hash, seed=5), O.mh_counts(sig)), (k, n_hash)
         rc, want = O.similarity_mh(seqs, k, n_hash, seeds)
         assert_same_f64(da.similarityMH(seqs, k, n_hash, seed=5), want)
-    with pytest.raises(da.DynaAlignError) as ei:
-        da.similarityMH(seqs, 4, 70000, seed=5)
-    assert ei.value.code == 10
+    # beyond the 16-bit counters of the compare kernels: chunked by the host entry point (the reference has no upper limit)
+    seeds = da.hash_family_seeds(5, 70000)
+    rc, want = O.similarity_mh(seqs, 4, 70000, seeds)
+    assert_same_f64(da.similarityMH(seqs, 4, 70000, seed=5), want)
 
 
 def test_mh_row_blocks_and_forced_streaming(da, monkeypatch):
