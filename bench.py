@@ -15,7 +15,7 @@ Headline workload (BASELINE.json configs[3], the one the metric is quoted on): 1
 k=4 n_hash=500, hash seed 12345.  The same JSON line also carries
     roofline      the dominant kernel (K2): algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak, + the VALU bound
     nw            similarityNW BLOSUM62/10/4 on the same set (second half of the metric) with its own roofline object
-    uniform       the other SURVEY 8(d) workload, S100k uniform (needs 16 code planes instead of 12)
+    uniform       the other SURVEY 8(d) workload, S100k uniform (16 code planes instead of 12: k_mh_compare_a16)
     t_h           the host-pointer boundary (what R sees): da_similarity_mh / _nw into a pageable host matrix, PCIe-inclusive
     edges         similarityMH + clusterbreak's quantile threshold as an edge list
     clusterbreak  BASELINE configs[4]: clusterbreak(size_max=800, thresh_p=.8) end to end on the device edge path
@@ -264,8 +264,8 @@ def main():
             tiles = sum(T - t for t in range(rank, T, world))
             bytes_k2 = wl_n * planes_row_bytes + tiles * 128 * 128 * 2   # this rank's uint16 tiles
         lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
-        # 12 code planes, symmetric mode: the hand-scheduled kernel does all but the diagonal / border tiles
-        k2_name = "k_mh_compare_a12<true>" if (world == 1 and plane_bits == 12) else "k_mh_compare<true, true, %d>" % plane_bits
+        # 12 / 16 code planes, symmetric mode: the hand-scheduled kernels do all but the diagonal / border tiles
+        k2_name = ("k_mh_compare_a%d<true>" % plane_bits) if (world == 1 and plane_bits in (12, 16)) else "k_mh_compare<true, true, %d>" % plane_bits
         traffic = pmc_traffic(k2_name, wl_n) if world == 1 else None
         return {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,

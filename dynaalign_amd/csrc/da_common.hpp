@@ -82,8 +82,26 @@ __host__ __device__ inline int64_t plane_unit_word(const PlaneGeom &g, int64_t r
   const int xs = g.segs == 4 ? (rs >> 2) & 3 : 0;
   return ((((row >> 7) * g.nst + st) * 128 + rs) * g.segs + (seg ^ xs)) * 4;
 }
-// uint32 words an operand buffer must hold for any plane count (the raw 32-plane layout is the largest)
-inline int64_t mh_planes_words(int64_t n, int n_hash) { return n > 0 && n_hash > 0 ? 2 * plane_geom(n, n_hash, 32).copy_words : 0; }
+// The hand-scheduled 16-plane kernel (k_mh_compare_a16) reads a PADDED twin of the 16-plane operand, stored behind the two
+// regular copies: same [block of 128 rows][stage][LDS slot] order, but 80-byte slots (16 plane words + 4 words of padding):
+// its 8-byte operand reads are then bank-conflict-free at plain immediate offsets and a wave's share of a stage is five 1 KiB
+// DMA pieces.  Row copy: plane p at word p; column copy: word p ^ 1 (pair-swapped like the regular column copy).
+constexpr int K2_PAD16_SLOT_WORDS = 20;
+__host__ __device__ inline int64_t pad16_copy_words(int64_t n, int n_hash) {
+  return ((n + 127) / 128) * (int64_t)((n_hash + 31) / 32) * 128 * K2_PAD16_SLOT_WORDS;
+}
+__host__ __device__ inline int64_t pad16_base_words(int64_t n, int n_hash) { return 2 * plane_geom(n, n_hash, 16).copy_words; }
+__host__ __device__ inline int64_t pad16_slot_word(int64_t n, int n_hash, int64_t row, int group) {   // first word of the row's slot
+  const int64_t nst = (n_hash + 31) / 32;
+  return (((row >> 7) * nst + group) * 128 + k2_slot((int)(row & 127))) * K2_PAD16_SLOT_WORDS;
+}
+// uint32 words an operand buffer must hold for any plane count (raw 32 planes, or 16 planes + their padded twin)
+inline int64_t mh_planes_words(int64_t n, int n_hash) {
+  if (n <= 0 || n_hash <= 0) return 0;
+  const int64_t raw = 2 * plane_geom(n, n_hash, 32).copy_words;
+  const int64_t p16 = pad16_base_words(n, n_hash) + 2 * pad16_copy_words(n, n_hash);
+  return raw > p16 ? raw : p16;
+}
 
 // Kernel launchers implemented in the .hip translation units.  All are
 // asynchronous on `stream`; argument checking is done by the C-ABI layer.

@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256) void k_ids_to_planes(const uint16_t *__restric
         const int64_t w = plane_unit_word(pg, i, g, p >> 2);
         planes[w + (p & 3)] = wa;
         planes[pg.copy_words + w + ((p & 3) ^ 1)] = wb;    // pair-swapped copy (see k_mh_compare)
+        if (pl == 16) {                                    // padded twin for k_mh_compare_a16 (da_common.hpp)
+          const int64_t ws = pad16_base_words(n, n_hash) + pad16_slot_word(n, n_hash, i, g);
+          planes[ws + p] = wa;
+          planes[ws + pad16_copy_words(n, n_hash) + (p ^ 1)] = wb;
+        }
       }
     }
   }

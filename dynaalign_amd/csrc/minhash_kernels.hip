@@ -294,6 +294,13 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring; afterwards counters, then the ratio table
   static_assert(sizeof(lds_ab) / (sizeof(double)) == K2_A12_TABLE_MAX, "launch_mh_compare's table guard must match the ring size");
   if (K2_PRO_PRIO) __builtin_amdgcn_s_setprio(K2_PRO_PRIO);
+#ifdef K2_FIRST_STAGGER   // experiment: de-correlate the first generation of workgroups (they all start together and a tile
+  // takes the same time everywhere, so their store phases would hit HBM as one burst, generation after generation)
+  if (blockIdx.x < (unsigned)K2_FIRST_STAGGER) {
+    const unsigned w = ((blockIdx.x * 2654435761u) >> 20) % 21u;
+    for (unsigned q = 0; q < w; ++q) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   K2_STAMP(0);
   K2_STAMP_HW();
   const int64_t bid = blockIdx.x;
@@ -430,6 +437,126 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   K2_STAMP(3);
 #undef tx
 #undef ty
+}
+
+// ---- 16 code planes (uniform-like data) with the same hand-allocated loop ---------------------------------------
+// k_mh_compare<.., 16> needs 168 VGPRs = 3 waves per SIMD (34.6 ms at N = 100k).  The generated block (K2ASM_PLANES=16,
+// k2_loop_p16.inc: 8 two-plane steps per stage) reads the PADDED twin of the operand (da_common.hpp: 80-byte slots), stages
+// it through a ring of TWO 20 KiB stages (40 KiB: four workgroups per CU) with five 1 KiB DMA pieces per wave and stage from a
+// wave-uniform SGPR base, and hands the counters over in v64..v95 like k_mh_compare_a12.  Symmetric mode, interior
+// off-diagonal tiles (a12_takes); diagonal / border tiles stay with k_mh_compare<.., 16> on the regular copies.
+#ifndef K2_LOOP_INC_16
+#define K2_LOOP_INC_16 "k2_loop_p16.inc"
+#endif
+constexpr int K2_A16_TABLE_MAX = 2 * 2 * K2_TILE * 80 / 8;   // doubles that fit the 40 KiB ring
+template <bool F64>
+__global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a16(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
+                                                                  void *__restrict__ out_v, int64_t ld, int64_t ntiles,
+                                                                  int64_t per_xcd) {
+  constexpr int SLOT = 80, STAGE_BYTES = 2 * K2_TILE * SLOT;
+  __shared__ __attribute__((aligned(16))) uint4 lds_ab[2 * STAGE_BYTES / 16];   // 40 KiB ring; afterwards the ratio table
+  static_assert(sizeof(lds_ab) / (sizeof(double)) == K2_A16_TABLE_MAX, "launch_mh_compare's table guard must match the ring size");
+  const int64_t bid = blockIdx.x;
+  const int T = (int)((n + K2_TILE - 1) / K2_TILE);
+  const int64_t L = (bid & 7) * per_xcd + (bid >> 3);
+  if (L >= ntiles) return;
+  const TileId tl = decode_tile(L, T, T, true);
+  if (!tl.valid || !a12_takes(tl.ti, tl.tj, n, ld, out_v, F64)) return;
+  const int64_t I0 = (int64_t)tl.ti * K2_TILE, J0 = (int64_t)tl.tj * K2_TILE;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tx0 = ((wave & 1) << 3) + (lane & 7), ty0 = ((wave >> 1) << 3) + (lane >> 3);
+  // wave-uniform DMA source: wave w stages LDS slots [64w, 64w + 64) = rows (w < 2, row copy) or columns (w >= 2, column copy)
+  const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)wave);
+  const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = (uint32_t)(K2_TILE * SLOT);
+  const uint64_t src = reinterpret_cast<uint64_t>(planes) +
+                       4u * (uint64_t)(pad16_base_words(n, n_hash) + (wave_u >= 2 ? pad16_copy_words(n, n_hash) : 0)) +
+                       (uint64_t)(wave_u >= 2 ? tl.tj : tl.ti) * nstage * stage_bytes + (wave_u & 1u) * (64u * SLOT);
+  const uint32_t sl = __builtin_amdgcn_readfirstlane((uint32_t)src), sh = __builtin_amdgcn_readfirstlane((uint32_t)(src >> 32));
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)lds_ab);
+  uint32_t mis[8][4];
+  uint32_t tid_after;
+  {
+    register uint32_t r120 asm("v120") = lds_base + (uint32_t)(ty0 * SLOT);
+    register uint32_t r121 asm("v121") = lds_base + (uint32_t)((K2_TILE + tx0) * SLOT);
+    register uint32_t r124 asm("v124") = (uint32_t)tid * 4u;
+#define K2_CNT(i) register uint32_t c##i asm("v" #i);
+    K2_CNT(64) K2_CNT(65) K2_CNT(66) K2_CNT(67) K2_CNT(68) K2_CNT(69) K2_CNT(70) K2_CNT(71) K2_CNT(72) K2_CNT(73) K2_CNT(74)
+    K2_CNT(75) K2_CNT(76) K2_CNT(77) K2_CNT(78) K2_CNT(79) K2_CNT(80) K2_CNT(81) K2_CNT(82) K2_CNT(83) K2_CNT(84) K2_CNT(85)
+    K2_CNT(86) K2_CNT(87) K2_CNT(88) K2_CNT(89) K2_CNT(90) K2_CNT(91) K2_CNT(92) K2_CNT(93) K2_CNT(94) K2_CNT(95)
+#undef K2_CNT
+    asm volatile(
+#include K2_LOOP_INC_16
+        : "=v"(c64), "=v"(c65), "=v"(c66), "=v"(c67), "=v"(c68), "=v"(c69), "=v"(c70), "=v"(c71), "=v"(c72), "=v"(c73), "=v"(c74),
+          "=v"(c75), "=v"(c76), "=v"(c77), "=v"(c78), "=v"(c79), "=v"(c80), "=v"(c81), "=v"(c82), "=v"(c83), "=v"(c84), "=v"(c85),
+          "=v"(c86), "=v"(c87), "=v"(c88), "=v"(c89), "=v"(c90), "=v"(c91), "=v"(c92), "=v"(c93), "=v"(c94), "=v"(c95)
+        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh),
+          "v"(r120), "v"(r121), "v"(r124)
+        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",   // m0 is saved in s47 and restored by the block
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",
+          "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+          "v117", "v118", "v119", "v122", "v123");
+    asm volatile("" : "+v"(r124));                               // lane ids are re-derived from the value that crossed the block
+    tid_after = r124 >> 2;
+    const uint32_t cnt[32] = {c64, c65, c66, c67, c68, c69, c70, c71, c72, c73, c74, c75, c76, c77, c78, c79,
+                              c80, c81, c82, c83, c84, c85, c86, c87, c88, c89, c90, c91, c92, c93, c94, c95};
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mis[r][c] = cnt[4 * r + c];
+  }
+  const uint32_t nn = (uint32_t)n_hash * 0x10001u;             // two match counts per register (no borrow: each <= n_hash)
+  const int tid_e = (int)tid_after, wave_e = tid_e >> 6, lane_e = tid_e & 63;
+  const int tx = ((wave_e & 1) << 3) + (lane_e & 7), ty = ((wave_e >> 1) << 3) + (lane_e >> 3);
+  if (F64) {
+    double *ratio = reinterpret_cast<double *>(lds_ab);
+    __syncthreads();                                           // everyone has left the ring: the area becomes the table
+    for (int c = tid_e; c <= n_hash; c += K2_THREADS) ratio[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
+    __syncthreads();
+    const char *tb = reinterpret_cast<const char *>(ratio);
+    double *out = reinterpret_cast<double *>(out_v);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                              // two of the lane's rows at a time keeps the epilogue in 128 VGPRs
+      double v0[8], v1[8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t m0 = nn - mis[2 * g][c], m1 = nn - mis[2 * g + 1][c];
+        v0[2 * c] = *reinterpret_cast<const double *>(tb + ((m0 << 3) & 0x7fff8u));
+        v0[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m0 >> 13) & 0x7fff8u));
+        v1[2 * c] = *reinterpret_cast<const double *>(tb + ((m1 << 3) & 0x7fff8u));
+        v1[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m1 >> 13) & 0x7fff8u));
+      }
+      double *orow = out + (I0 + 32 * g + 2 * ty) * ld + (J0 + 2 * tx);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        nt_store2(orow + 32 * q, v0[2 * q], v0[2 * q + 1]);
+        nt_store2(orow + ld + 32 * q, v1[2 * q], v1[2 * q + 1]);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)                              // mirrored store (src/minHash.cpp:176)
+        nt_store2(out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 32 * g + 2 * ty), v0[c], v1[c]);
+    }
+  } else {
+    uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint16_t *orow = out + (I0 + 32 * (r >> 1) + 2 * ty + (r & 1)) * ld + (J0 + 2 * tx);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - mis[r][g];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      uint16_t *orow = out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 2 * ty);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t lo = mis[2 * g][c >> 1], hi = mis[2 * g + 1][c >> 1];
+        const uint32_t pk = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - pk;
+      }
+    }
+  }
 }
 
 // ---- the same 12-plane loop, PERSISTENT: a workgroup walks a sequence of tiles and its DMA ring never drains ----
@@ -1113,6 +1240,16 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   const bool a12 = symmetric && plane_bits == 12 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
                    (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A12_TABLE_MAX) &&
                    (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;   // = a12_takes' alignment test
+  // symmetric 16-plane compares likewise (k_mh_compare_a16 on the padded twin of the operand)
+  const bool a16 = symmetric && plane_bits == 16 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+                   (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A16_TABLE_MAX) &&
+                   (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;
+  if (a16) {
+    if (kind == DA_OUT_F64)
+      hipLaunchKernelGGL(k_mh_compare_a16<true>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
+    else
+      hipLaunchKernelGGL(k_mh_compare_a16<false>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
+  }
   // the persistent form of that kernel: >= 2 stages per tile, float64 needs its 4 KiB table (n_hash <= 511)
   // OPT-IN (DYNAALIGN_K2_PERSIST=1): measured slower than one tile per workgroup on MI355X -- 28.8 vs 24.9 ms (float64),
   // 26.3 vs 22.2 ms (uint16) at N = 100k (profiles/r02_c_k2_persistent_*.json): a wave that does not exit has to
@@ -1151,9 +1288,9 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
     else
       hipLaunchKernelGGL(k_mh_compare_a12<false>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
   }
-  const int only_edge = a12 ? 1 : 0;
+  const int only_edge = (a12 || a16) ? 1 : 0;
   // what is left for the general kernel then: the diagonal tiles + the last tile column, enumerated directly
-  if (a12) grid = dim3((unsigned)(2 * (int64_t)T - 1));
+  if (a12 || a16) grid = dim3((unsigned)(2 * (int64_t)T - 1));
 #define DA_K2(SYM, F64, PL)                                                                              \
   hipLaunchKernelGGL((k_mh_compare<SYM, F64, PL>), grid, block, 0, stream, d_planes, n, n_hash, \
                      row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, d_out, ld, ntiles, per_xcd, fold_q, fold_w, band, only_edge)

@@ -228,7 +228,8 @@ def test_crafted_signature_columns(da, n):
 
 @pytest.mark.parametrize("n,n_hash", [(1000, 500), (1153, 70), (2048, 33), (640, 31), (2500, 64), (3001, 129), (1300, 511), (1300, 512),
                                       (5000, 500)])
-def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash):
+@pytest.mark.parametrize("bits", [12, 16])
+def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash, bits):
     """symmetric 12-plane compares run a hand-scheduled stage loop on interior tiles and the compiled kernel on diagonal /
     border tiles.  Three routes, same operand: the one-tile-per-workgroup k_mh_compare_a12 (default), the PERSISTENT kernel
     k_mh_compare_p12 (DYNAALIGN_K2_PERSIST=1; a workgroup walks a sequence of tiles, ring never drains; n_hash <= 32 and
@@ -238,8 +239,8 @@ def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash):
     import torch
     from dynaalign_amd import device, synth, _capi
     res, off = synth.h3n2_like(n, 20)
-    n, sig_h, p12, p32 = _planes_both(da, res, off, 4, n_hash, min_bits=12)
-    assert p12.bits == 12
+    n, sig_h, p12, p32 = _planes_both(da, res, off, 4, n_hash, min_bits=bits)
+    assert p12.bits == bits          # 16: k_mh_compare_a16 on the padded twin of the operand (8 steps per stage, ring of two stages)
     want = _counts(sig_h) if n <= 3100 else None
     got = {}
     for tag, env in (("persistent", "DYNAALIGN_K2_PERSIST"), ("one_tile", None), ("compiled", "DYNAALIGN_K2_NO_ASM")):

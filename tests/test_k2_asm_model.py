@@ -41,3 +41,20 @@ def test_committed_persistent_include_is_the_generators_output(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
                           stdout=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p12p.inc")).read()
+
+
+@pytest.mark.parametrize("ns,tx,ty", [(16, 0, 0), (1, 5, 11), (2, 15, 15), (3, 7, 8), (5, 9, 4)])
+def test_16_plane_block(ns, tx, ty):
+    """the block of k_mh_compare_a16: padded 80-byte slots, ring of two stages, five DMA pieces per wave and stage"""
+    import sim_k2_asm
+    issued, bad = sim_k2_asm.run16(tx, ty, seed=ns, ns=ns)
+    assert issued == ns and bad == 0
+
+
+def test_committed_16_plane_include_is_the_generators_output(tmp_path):
+    out = tmp_path / "k2_16.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("K2ASM_")}
+    env["K2ASM_PLANES"] = "16"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
+                          stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p16.inc")).read()

@@ -34,9 +34,18 @@ PERSIST = int(os.environ.get("K2ASM_PERSIST", "0"))   # 1: the block of the PERS
 if PERSIST:
     SADDR = 1
     REGOUT = 1
-SEGS, STEPS = 3, 6           # 12 planes: 3 segments of 16 bytes = 6 steps of 8 bytes
-STAGE_BYTES = 256 * SEGS * 16  # 12288
-ROW = 16 * SEGS * 16          # byte distance between the lane's rows / columns in LDS: 768
+PLANES = int(os.environ.get("K2ASM_PLANES", "12"))   # 16: the block of k_mh_compare_a16 (uniform-like data: column dictionaries
+# of up to 65 534 values).  Its operand is a PADDED copy of the 16 code planes: 80-byte LDS slots (64 bytes of planes + 16 of
+# padding) make the loop's 8-byte operand reads bank-conflict-free with plain immediate offsets (the 64-byte slots of the
+# compiled kernel need an XOR swizzle that an immediate cannot express), a wave's share of a stage is exactly five 1 KiB DMA
+# pieces, and a ring of TWO 20 KiB stages keeps four workgroups per CU.  SGPR-base DMA form, counters out in registers.
+if PLANES == 16:
+    SADDR = 1
+    REGOUT = 1
+    assert not PERSIST
+SEGS, STEPS = (3, 6) if PLANES == 12 else (5, 8)   # 16-byte units per LDS slot; 2-plane steps per stage
+STAGE_BYTES = 256 * SEGS * 16  # 12288 (20480 with the padded 16-plane slots)
+ROW = 16 * SEGS * 16          # byte distance between the lane's rows / columns in LDS: 768 (1280)
 out = []
 def e(x):
     out.append(x)
@@ -254,8 +263,70 @@ def gen_persistent():
     e("9:")
     e("s_mov_b32 m0, s47")
 
+def gen_16():
+    e("// generated by tools/gen_k2_asm.py (K2ASM_PLANES=16) -- do not edit")
+    e("s_mov_b32 s47, m0")
+    if PRIO:
+        e("s_setprio %d" % PRIO)
+    e("s_mov_b32 %s, 0" % S_STAGE)
+    e("v_and_b32 v118, 0xfc, v124")          # 16 * lane: this lane's offset inside the wave's 1 KiB piece
+    e("v_lshlrev_b32 v118, 2, v118")
+    for r in range(8):
+        for c2 in range(4):
+            e("v_mov_b32 %s, 0" % mis(r, c2))
+    e("s_mul_i32 %s, %%[wv], %d" % (S_TMP, SEGS * 1024))
+    e("s_add_u32 s46, %[lb], " + S_TMP)                 # ring + this wave's part of a stage (5 KiB)
+    e("s_mov_b32 s48, %[sl]")
+    e("s_mov_b32 s49, %[sh]")
+    def issue5():
+        for q in range(SEGS):
+            e("s_add_u32 m0, %s, %d" % (S_M0, q * 1024))
+            e("s_add_u32 s50, s48, %d" % (q * 1024))
+            e("s_addc_u32 s51, s49, 0")
+            e("global_load_lds_dwordx4 v118, s[50:51]")
+        e("s_add_u32 s48, s48, %[st]")
+        e("s_addc_u32 s49, s49, 0")
+    e("s_mov_b32 %s, s46" % S_M0)
+    issue5()                                             # stage 0 -> ring slot 0
+    e("s_mov_b32 %s, 0" % S_SLOT)
+    e("s_mov_b32 %s, %d" % (S_ISSUE_SLOT, STAGE_BYTES))
+    e("2:")
+    e("s_waitcnt vmcnt(0)")                              # two-stage ring: only the stage about to be computed is in flight
+    e("s_barrier")
+    e("v_add_u32 v116, %s, v120" % S_SLOT)
+    e("v_add_u32 v117, %s, v121" % S_SLOT)
+    b_read(0, 0, 0)
+    b_read(1, 0, 1)
+    for r in range(8):
+        e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
+    e("s_add_u32 %s, %s, 1" % (S_TMP, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
+    e("s_cbranch_scc0 5f")
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))   # the other slot: everyone left it before this stage's barrier
+    issue5()
+    e("5:")
+    e("s_cmp_eq_u32 %s, 0" % S_STAGE)
+    e("s_cbranch_scc1 6f")
+    count_group()
+    e("6:")
+    cur = 0
+    for k in range(STEPS):
+        cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)   # every stage starts again with buffer 0 (fresh preload)
+    e("s_xor_b32 %s, %s, %d" % (S_SLOT, S_SLOT, STAGE_BYTES))
+    e("s_xor_b32 %s, %s, %d" % (S_ISSUE_SLOT, S_ISSUE_SLOT, STAGE_BYTES))
+    e("s_add_u32 %s, %s, 1" % (S_STAGE, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
+    e("s_cbranch_scc1 2b")
+    count_group()
+    if PRIO or EPRIO:
+        e("s_setprio %d" % EPRIO)
+    e("s_mov_b32 m0, s47")
+
+
 if PERSIST:
     gen_persistent()
+elif PLANES == 16:
+    gen_16()
 else:
     e("// generated by tools/gen_k2_asm.py -- do not edit")
     e("s_mov_b32 s47, m0")                                # m0 is compiler-reserved: saved here, restored at the end of the block

@@ -18,17 +18,26 @@ INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 INC_P = os.path.join(os.path.dirname(INC), "k2_loop_p12p.inc")
 
 
-def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P):
+INC_16 = os.path.join(os.path.dirname(INC), "k2_loop_p16.inc")
+
+
+def run16(tx=5, ty=11, seed=1, ns=16):
+    """The 16-plane block (K2ASM_PLANES=16, k_mh_compare_a16): padded 80-byte slots, ring of two stages, five DMA pieces"""
+    return run_persistent(tx, ty, seed, ntiles=1, ns=ns, inc=INC_16, planes=16, slot_bytes=80, ring=2)
+
+
+def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, slot_bytes=48, ring=3):
     """The block of the persistent kernel (K2ASM_PERSIST=1), executed `ntiles` times in a row on one LDS image, the
     way k_mh_compare_p12 calls it: flags first / has-next, ring phase advancing by ns stages per tile, the next tile's
     source handed in.  The DMA is modelled by ADDRESS: the stage image that appears in the ring is the one the running
     source base points at, so a wrong base switch or ring slot shows up as wrong counters.  Returns (stages issued,
     wrong counters)."""
     lines = [l.strip()[1:].split('\\n')[0] for l in open(inc) if l.startswith('"')]
-    STAGE = 12288; LB = 4096; ST = 6144; TILE_STRIDE = 1 << 24
+    STAGE = 256 * slot_bytes; LB = 4096; ST = 128 * slot_bytes; TILE_STRIDE = 1 << 24
+    pieces = 64 * slot_bytes // 1024
     random.seed(seed)
     stages = [[bytes(random.getrandbits(8) for _ in range(STAGE)) for _ in range(ns)] for _ in range(ntiles)]
-    lds = bytearray(LB + 3 * STAGE)
+    lds = bytearray(LB + ring * STAGE)
     labels = {}
     for i, l in enumerate(lines):
         m = re.match(r'^(\d+):$', l)
@@ -44,7 +53,7 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P):
         base = (t + 1) * TILE_STRIDE; nbase = (t + 2) * TILE_STRIDE
         S['sl'], S['sh'] = base & 0xffffffff, base >> 32
         S['nl'], S['nh'] = nbase & 0xffffffff, nbase >> 32
-        V[120] = LB + ty * 48; V[121] = LB + (128 * 3 + tx * 3) * 16; V[124] = 0
+        V[120] = LB + ty * slot_bytes; V[121] = LB + (128 + tx) * slot_bytes; V[124] = 0
         def sval(x):
             x = x.strip()
             if x.startswith('%['): return S[x[2:-1]]
@@ -65,6 +74,7 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P):
             elif op == 's_addc_u32':
                 r = sval(a[1]) + sval(a[2]) + scc; S[a[0]] = r & 0xffffffff; scc = int(r > 0xffffffff)
             elif op == 's_sub_u32': S[a[0]] = (sval(a[1]) - sval(a[2])) & 0xffffffff
+            elif op == 's_xor_b32': S[a[0]] = sval(a[1]) ^ sval(a[2])
             elif op == 's_mul_i32': S[a[0]] = (sval(a[1]) * sval(a[2])) & 0xffffffff
             elif op == 's_cmp_lt_u32': scc = int(sval(a[0]) < sval(a[1]))
             elif op == 's_cmp_eq_u32': scc = int(sval(a[0]) == sval(a[1]))
@@ -87,12 +97,12 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P):
                     tt, off = addr // TILE_STRIDE - 1, addr % TILE_STRIDE
                     assert off % ST == 0 and 0 <= tt < ntiles and off // ST < ns, "DMA source outside any stage: %x" % addr
                     slot, rem = divmod(S['m0'] - LB, STAGE)
-                    assert rem == 0 and 0 <= slot < 3, "DMA destination outside the ring: %x" % S['m0']
+                    assert rem == 0 and 0 <= slot < ring, "DMA destination outside the ring: %x" % S['m0']
                     lds[LB + slot * STAGE:LB + (slot + 1) * STAGE] = stages[tt][off // ST]
                     issued_total += 1
                 else:
                     assert addr % TILE_STRIDE % ST == piece * 1024
-                piece = (piece + 1) % 3
+                piece = (piece + 1) % pieces
             elif op == 'v_add_u32':
                 x = sval(a[1]) if not a[1].startswith('v') else V[vreg(a[1])]
                 V[vreg(a[0])] = (x + V[vreg(a[2])]) & 0xffffffff
@@ -111,18 +121,18 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P):
             else:
                 raise RuntimeError("unhandled instruction: " + l)
         def word(stage, slot, w):
-            o = slot * 48 + w * 4; return int.from_bytes(stages[t][stage][o:o + 4], 'little')
+            o = slot * slot_bytes + w * 4; return int.from_bytes(stages[t][stage][o:o + 4], 'little')
         for r in range(8):
             for c in range(8):
                 arow = r * 16 + ty; bcol = 128 + c * 16 + tx
                 mism = 0
                 for st in range(ns):
                     dd = 0
-                    for pl in range(12):
+                    for pl in range(planes):
                         dd |= word(st, arow, pl) ^ word(st, bcol, pl ^ 1)
                     mism += bin(dd).count('1')
                 if ((V[64 + 4 * r + c // 2] >> (16 * (c & 1))) & 0xffff) != mism: bad += 1
-        phase = (phase + ns) % 3
+        phase = (phase + ns) % ring
     return issued_total, bad
 
 
@@ -227,4 +237,6 @@ if __name__ == "__main__":
     print("stages issued", issued, "wrong counters", bad)
     pissued, pbad = run_persistent()
     print("persistent block, 3 tiles: stages issued", pissued, "wrong counters", pbad)
-    sys.exit(1 if bad or issued != 16 or pbad or pissued != 48 else 0)
+    i16, b16 = run16()
+    print("16-plane block: stages issued", i16, "wrong counters", b16)
+    sys.exit(1 if bad or issued != 16 or pbad or pissued != 48 or b16 or i16 != 16 else 0)
