@@ -23,11 +23,13 @@
 // and all floating-point sums run in that canonical order -- the same graph and seed give the same
 // membership whatever order the edges arrive in (the device appends edges in arrival order).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "da_common.hpp"
@@ -96,25 +98,58 @@ int build_graph(int64_t n, int64_t m, const int32_t *ei, const int32_t *ej, cons
   }
   std::sort(loops.begin(), loops.end());
   for (const auto &l : loops) g.loop[(size_t)l.first] += l.second;
-  // sort each neighbour list by (id, weight) and merge duplicates
-  std::vector<std::pair<int32_t, double>> tmp;
-  int64_t out = 0;
-  std::vector<int64_t> nptr((size_t)n + 1, 0);
-  for (int64_t v = 0; v < n; ++v) {
-    const int64_t b = g.ptr[(size_t)v], e = g.ptr[(size_t)v + 1];
-    tmp.clear();
-    for (int64_t k = b; k < e; ++k) tmp.emplace_back(g.adj[(size_t)k], g.w[(size_t)k]);
-    std::sort(tmp.begin(), tmp.end());
-    nptr[(size_t)v] = out;
-    for (size_t k = 0; k < tmp.size(); ++k) {
-      if (out > nptr[(size_t)v] && g.adj[(size_t)out - 1] == tmp[k].first) g.w[(size_t)out - 1] += tmp[k].second;
-      else { g.adj[(size_t)out] = tmp[k].first; g.w[(size_t)out] = tmp[k].second; ++out; }
+  // sort each neighbour list by (id, weight) -- vertices are independent, so a few host threads share them (the result does
+  // not depend on the thread count) -- then merge duplicate entries, sequentially and only if there are any
+  {
+    int nthreads = (int)std::min<int64_t>(16, std::max<int64_t>(1, (int64_t)g.adj.size() / 2000000));
+    if (const char *e = getenv("DYNAALIGN_LOUVAIN_THREADS")) nthreads = std::max(1, atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 0 && (unsigned)nthreads > hw) nthreads = (int)hw;
+    std::atomic<int> any_dup(0);
+    auto work = [&](int t) {
+      std::vector<std::pair<int32_t, double>> tmp;
+      bool dup = false;
+      // contiguous ranges of roughly equal adjacency volume
+      const int64_t total_adj = (int64_t)g.adj.size();
+      const int64_t lo = total_adj * t / nthreads, hi = total_adj * (t + 1) / nthreads;
+      int64_t v0 = std::lower_bound(g.ptr.begin(), g.ptr.end() - 1, lo) - g.ptr.begin();
+      int64_t v1 = (t + 1 == nthreads) ? n : std::lower_bound(g.ptr.begin(), g.ptr.end() - 1, hi) - g.ptr.begin();
+      for (int64_t v = v0; v < v1; ++v) {
+        const int64_t b = g.ptr[(size_t)v], e = g.ptr[(size_t)v + 1];
+        tmp.clear();
+        for (int64_t k = b; k < e; ++k) tmp.emplace_back(g.adj[(size_t)k], g.w[(size_t)k]);
+        std::sort(tmp.begin(), tmp.end());
+        for (int64_t k = b; k < e; ++k) {
+          g.adj[(size_t)k] = tmp[(size_t)(k - b)].first;
+          g.w[(size_t)k] = tmp[(size_t)(k - b)].second;
+          if (k > b && g.adj[(size_t)k] == g.adj[(size_t)k - 1]) dup = true;
+        }
+      }
+      if (dup) any_dup.store(1);
+    };
+    if (nthreads <= 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+      for (auto &x : th) x.join();
+    }
+    if (any_dup.load()) {
+      int64_t out = 0;
+      std::vector<int64_t> nptr((size_t)n + 1, 0);
+      for (int64_t v = 0; v < n; ++v) {
+        const int64_t b = g.ptr[(size_t)v], e = g.ptr[(size_t)v + 1];
+        nptr[(size_t)v] = out;
+        for (int64_t k = b; k < e; ++k) {
+          if (out > nptr[(size_t)v] && g.adj[(size_t)out - 1] == g.adj[(size_t)k]) g.w[(size_t)out - 1] += g.w[(size_t)k];
+          else { g.adj[(size_t)out] = g.adj[(size_t)k]; g.w[(size_t)out] = g.w[(size_t)k]; ++out; }
+        }
+      }
+      nptr[(size_t)n] = out;
+      g.ptr.swap(nptr);
+      g.adj.resize((size_t)out);
+      g.w.resize((size_t)out);
     }
   }
-  nptr[(size_t)n] = out;
-  g.ptr.swap(nptr);
-  g.adj.resize((size_t)out);
-  g.w.resize((size_t)out);
   g.total = 0.0;
   for (int64_t v = 0; v < n; ++v) {
     double k = 2.0 * g.loop[(size_t)v];
@@ -150,12 +185,22 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
   const int32_t n = g.n;
   comm.resize((size_t)n);
   std::iota(comm.begin(), comm.end(), 0);
-  std::vector<double> k((size_t)n), tot((size_t)n);
+  // per community: tot = sum of member strengths, in = internal weight (every internal edge twice, loops twice) -- both
+  // kept up to date move by move, so the modularity after a pass costs O(n) instead of another sweep over all edges
+  std::vector<double> k((size_t)n), tot((size_t)n), in((size_t)n);
   for (int32_t v = 0; v < n; ++v) {
     double s = 2.0 * g.loop[(size_t)v];
     for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) s += g.w[(size_t)q];
     k[(size_t)v] = tot[(size_t)v] = s;
+    in[(size_t)v] = 2.0 * g.loop[(size_t)v];
   }
+  auto modularity_now = [&]() {
+    double Q = 0.0;
+    for (int32_t c = 0; c < n; ++c)
+      if (tot[(size_t)c] != 0.0 || in[(size_t)c] != 0.0)
+        Q += in[(size_t)c] / g.total - resolution * (tot[(size_t)c] / g.total) * (tot[(size_t)c] / g.total);
+    return Q;
+  };
   std::vector<int32_t> order((size_t)n);
   std::iota(order.begin(), order.end(), 0);
   for (int32_t i = 0; i + 1 < n; ++i) {                       // Fisher-Yates on raw mt19937 draws
@@ -168,7 +213,7 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
   *moved = false;
   const double m2 = g.total;
   if (m2 <= 0.0) return n;
-  double q_prev = modularity_of(g, comm, resolution);
+  double q_prev = modularity_now();
   for (;;) {
     int64_t changed = 0;
     for (int32_t idx = 0; idx < n; ++idx) {
@@ -191,13 +236,18 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
       }
       tot[(size_t)best] += kv;
       comm[(size_t)v] = best;
-      if (best != old) ++changed;
+      if (best != old) {
+        ++changed;
+        const double lv = 2.0 * g.loop[(size_t)v];
+        in[(size_t)old] -= 2.0 * wto[(size_t)old] + lv;
+        in[(size_t)best] += 2.0 * wto[(size_t)best] + lv;
+      }
       for (int32_t c : touched) { wto[(size_t)c] = 0.0; seen[(size_t)c] = 0; }
     }
     if (getenv("DYNAALIGN_LOUVAIN_DEBUG")) fprintf(stderr, "[louvain] n=%d pass: %lld moved\n", n, (long long)changed);
     if (changed == 0) break;
     *moved = true;
-    const double q_now = modularity_of(g, comm, resolution);
+    const double q_now = modularity_now();
     if (!(q_now > q_prev)) break;                               // igraph: keep passing only while modularity improves
     q_prev = q_now;
   }
