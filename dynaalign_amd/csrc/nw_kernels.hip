@@ -24,6 +24,7 @@
 //   * only pairs with i <= j are evaluated, as calc(seq[i], seq[j])
 //     (reference :340-346; the function is not symmetric); the
 //     mirrored element is stored from the same lane (:349-350).
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 
@@ -610,6 +611,173 @@ __global__ __launch_bounds__(K4_THREADS) void k_nw_long(
   }
 }
 
+// ---------------------------------------------------------------- K5 --
+// k_nw_xlong: sequences beyond k_nw_long's 64 lanes x 16 columns (the reference is O(m n) for ANY length,
+// src/pairwiseSeqAlign.cpp:216-219).  Same systolic sweep, tiled along sequence2: column blocks of 1024; the last column of a
+// block (M - goe, Iy, matches/length for every row) is spilled to HBM by lane 63 and read back by lane 0 as the left boundary
+// of the next block -- the "rolling kernel with HBM spill" of SURVEY 8(f)-4.  sequence1 sits in dynamic LDS (any length the
+// 160 KiB hold: 4 waves x max_len bytes), workgroups walk the tile list with a grid stride so the spill area is per resident
+// wave.  Alignment length is carried in 16 bits like everywhere else, hence m + n <= 65535 (max_len <= 32767).
+constexpr int K5_W = 16, K5_CB = 64 * K5_W;
+constexpr int K5_MAXLEN = 32767;
+__global__ __launch_bounds__(K4_THREADS) void k_nw_xlong(
+    const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n, ScoreTable table,
+    int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric, int kind,
+    void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out, int64_t ld_score,
+    int64_t ntiles, int T, int32_t *__restrict__ bnd, int64_t bnd_stride, int s1cap) {
+  constexpr int W = K5_W;
+  __shared__ __attribute__((aligned(16))) Cell tab[24 * 24];
+  extern __shared__ uint8_t seq1_dyn[];
+  const int32_t goe = go + ge;
+  const int32_t NEG = INT_MIN / 2;
+  const int32_t ix_first = max(NEG - goe, NEG - ge);
+  for (int e = threadIdx.x; e < 576; e += K4_THREADS) {
+    const int a = e / 24, b = e - a * 24;
+    tab[e].s_goe = (int32_t)table.s[e] + goe;
+    tab[e].inc = 1u + ((a == b) ? 0x10000u : 0u);
+  }
+  __syncthreads();
+  const char *tab_bytes = reinterpret_cast<const char *>(tab);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t *s1 = seq1_dyn + (size_t)wave * s1cap;
+  int32_t *bm = bnd + ((int64_t)blockIdx.x * 4 + wave) * 3 * bnd_stride, *by = bm + bnd_stride, *bp = by + bnd_stride;
+
+  for (int64_t L = blockIdx.x; L < ntiles; L += gridDim.x) {
+    int ti, tj;
+    bool allow_direct = true, allow_mirror = true;
+    if (symmetric) {  // row-major over the upper triangle of 8x8-pair tiles
+      const double Td = (double)T;
+      int64_t t = (int64_t)(Td + 0.5 - sqrt((Td + 0.5) * (Td + 0.5) - 2.0 * (double)L));
+      if (t < 0) t = 0;
+      if (t > T - 1) t = T - 1;
+      auto start = [&](int64_t r) { return r * T - r * (r - 1) / 2; };
+      while (t > 0 && start(t) > L) --t;
+      while (t + 1 <= T - 1 && start(t + 1) <= L) ++t;
+      ti = (int)t;
+      tj = (int)(t + (L - start(t)));
+    } else {          // row block: see k_nw_short
+      const int rt = (int)(row_begin / K4_TILE) + (int)(L / T);
+      const int tc = (int)(L % T);
+      ti = tc >= rt ? rt : tc;
+      tj = tc >= rt ? tc : rt;
+      allow_direct = tc >= rt;
+      allow_mirror = tc <= rt;
+    }
+    const int64_t I0 = (int64_t)ti * K4_TILE, J0 = (int64_t)tj * K4_TILE;
+    for (int ri = 0; ri < 2; ++ri) {
+      const int64_t i = I0 + wave * 2 + ri;
+      if (i >= n) break;
+      const int64_t b1 = offsets[i];
+      const int32_t m = (int32_t)(offsets[i + 1] - b1);
+      for (int q = lane; q < m; q += 64) s1[q] = codes[b1 + q];   // same wave reads it back: program order suffices
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int cj = 0; cj < K4_TILE; ++cj) {
+        const int64_t j = J0 + cj;
+        if (j >= n || j < i) continue;
+        const bool do_direct = allow_direct && i >= row_begin && i < row_end;
+        const bool do_mirror = allow_mirror && j != i && j >= row_begin && j < row_end;
+        if (!do_direct && !do_mirror) continue;
+        const int64_t b2 = offsets[j];
+        const int32_t nn = (int32_t)(offsets[j + 1] - b2);
+        uint32_t p_res = 0;       // matches<<16 | len of cell (m, nn)
+        int32_t sc_res = NEG;
+        if (m == 0 || nn == 0) {  // boundary cells (reference :222-235)
+          p_res = (uint32_t)(m == 0 ? nn : m);
+          sc_res = (m == 0 && nn == 0) ? 0 : NEG;
+        } else {
+          const int nblk = (nn + K5_CB - 1) / K5_CB;
+          int own_lane = 0;
+          for (int cb = 0; cb < nblk; ++cb) {
+            const int c0 = cb * K5_CB;
+            const int ncol = (nn - c0 < K5_CB) ? (nn - c0) : K5_CB;
+            const int la = (ncol + W - 1) / W;          // lanes that own at least one real column of this block
+            const int c_first = c0 + lane * W;          // 0-based index of this lane's first column
+            const bool last_blk = cb + 1 == nblk;
+            uint32_t boff[W];
+            int32_t MG[W], X[W];
+            uint32_t P[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              const int c = c_first + w;                // column c+1
+              boff[w] = (c < nn ? (uint32_t)codes[b2 + c] : 0u) * (uint32_t)sizeof(Cell);
+              MG[w] = max(NEG, -go - c * ge) - goe;     // max(M,Ix,Iy)[0][c+1] - goe
+              X[w] = NEG;
+              P[w] = (uint32_t)(c + 1);
+            }
+            int32_t mg_prev = (c_first == 0) ? -goe : (max(NEG, -go - (c_first - 1) * ge) - goe);  // max(M,Ix,Iy)[0][c_first] - goe
+            uint32_t p_prev = (uint32_t)c_first;
+            int32_t mg_send = 0, y_send = 0;
+            uint32_t p_send = 0;
+            own_lane = (ncol - 1) / W;
+            const int own_w = (ncol - 1) - own_lane * W;
+            const int steps = m + la - 1;
+            for (int t = 0; t < steps; ++t) {
+              int32_t mg_in = __shfl_up(mg_send, 1);
+              int32_t y_in = __shfl_up(y_send, 1);
+              uint32_t p_in = (uint32_t)__shfl_up((int)p_send, 1);
+              const int r = t - lane + 1;             // DP row of this lane in this step
+              if (lane == 0) {
+                if (cb == 0) { mg_in = NEG - goe; y_in = NEG; p_in = (uint32_t)r; }        // column 0 (reference :224-229)
+                else if (r >= 1 && r <= m) {                                                 // last column of the previous block
+                  mg_in = __hip_atomic_load(bm + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  y_in = __hip_atomic_load(by + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  p_in = (uint32_t)__hip_atomic_load(bp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
+              if (lane < la && r >= 1 && r <= m) {
+                const uint32_t a = s1[r - 1];
+                const char *tab_row = tab_bytes + a * (24u * (uint32_t)sizeof(Cell));
+                int32_t y_out;
+                if (r == 1)
+                  nw_row<W, true>(MG, X, P, boff, tab_row, mg_prev, p_prev, p_in, mg_in, y_in, ge, goe, ix_first, &y_out);
+                else
+                  nw_row<W, false>(MG, X, P, boff, tab_row, mg_prev, p_prev, p_in, mg_in, y_in, ge, goe, ix_first, &y_out);
+                // column c_first at row r becomes the diagonal neighbour of row r+1
+                mg_prev = (c_first == 0) ? (max(NEG, -go - (r - 1) * ge) - goe) : mg_in;   // column 0: max(M,Ix,Iy)[r][0] = Ix[r][0]
+                p_prev = p_in;
+                mg_send = MG[W - 1];
+                y_send = y_out;
+                p_send = P[W - 1];
+                if (!last_blk && lane == 63) {          // a full block: lane 63 owns its last column
+                  __hip_atomic_store(bm + r, mg_send, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(by + r, y_send, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(bp + r, (int32_t)p_send, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (last_blk && r == m && lane == own_lane) {
+#pragma unroll
+                  for (int w = 0; w < W; ++w)
+                    if (w == own_w) { p_res = P[w]; sc_res = MG[w] + goe; }
+                }
+              }
+            }
+            if (!last_blk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the spilled column is complete before lane 0 reads it
+          }
+          p_res = (uint32_t)__shfl((int)p_res, own_lane);
+          sc_res = __shfl(sc_res, own_lane);
+        }
+        if (lane == 0) {
+          const uint32_t mt = p_res >> 16, ln = p_res & 0xffffu;
+          const int64_t od = (i - row_begin) * ld + j, om = (j - row_begin) * ld + i;
+          if (kind == DA_OUT_F64) {
+            const double v = nw_ratio(mt, ln);
+            if (do_direct) reinterpret_cast<double *>(out_v)[od] = v;
+            if (do_mirror) reinterpret_cast<double *>(out_v)[om] = v;
+          } else if (kind == DA_OUT_PACK32) {
+            if (do_direct) reinterpret_cast<uint32_t *>(out_v)[od] = p_res;
+            if (do_mirror) reinterpret_cast<uint32_t *>(out_v)[om] = p_res;
+          }
+          if (score_out) {
+            if (do_direct) score_out[(i - row_begin) * ld_score + j] = sc_res;
+            if (do_mirror) score_out[(j - row_begin) * ld_score + i] = sc_res;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // next row overwrites s1
+    }
+  }
+}
+
 // ---------------------------------------------------------------- duplicate sequences --
 // Byte-identical sequences have identical rows and columns in the result, so the DP only has to run on the table of
 // UNIQUE sequences and the N x N matrix is an index expansion of it (same spirit as the MinHash dictionary; exact).
@@ -825,10 +993,36 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   if (n <= 0 || row_end <= row_begin) return DA_OK;
   const signed char *tab = matrix_table_host(matrix_id);
   if (!tab) return fail(DA_ERR_BAD_ARG, "matrix id %d out of range", matrix_id);
-  if (max_len > K4_MAXLEN)
+  if (max_len > K5_MAXLEN)
     return fail(DA_ERR_UNSUPPORTED,
-                "similarityNW on gfx950 handles sequences up to %d residues (longest here: %lld)", K4_MAXLEN,
-                (long long)max_len);
+                "similarityNW on gfx950 carries the alignment length in 16 bits: sequences up to %d residues (longest here: %lld)",
+                K5_MAXLEN, (long long)max_len);
+  if (max_len > K4_MAXLEN) {   // column-blocked sweep with the block boundary spilled to HBM (k_nw_xlong); synchronises the stream
+    if (ord_first || shard_world > 0) return fail(DA_ERR_UNSUPPORTED, "sequences > %d residues: dense / row-block output only", K4_MAXLEN);
+    if (kind == DA_OUT_COMPACT) return fail(DA_ERR_UNSUPPORTED, "uint16 NW output needs alignment length <= 255 (use the float64 or 32-bit packed kind)");
+    ScoreTable st5;
+    for (int e = 0; e < 576; ++e) st5.s[e] = tab[e];
+    const int T8 = (int)ceil_div(n, K4_TILE);
+    int64_t nt;
+    if (symmetric) nt = (int64_t)T8 * (T8 + 1) / 2;
+    else nt = ((row_end - 1) / K4_TILE - row_begin / K4_TILE + 1) * (int64_t)T8;
+    const int s1cap = (int)ceil_div(max_len, 64) * 64;
+    const size_t dyn = (size_t)4 * s1cap;
+    const unsigned grid5 = (unsigned)std::min<int64_t>(nt, 1024);
+    const int64_t bnd_stride = max_len + 1;
+    int32_t *d_bnd = nullptr;
+    DA_HIP_TRY(hipMalloc(&d_bnd, (size_t)grid5 * 4 * 3 * (size_t)bnd_stride * sizeof(int32_t)));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_nw_xlong), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_nw_xlong, dim3(grid5), dim3(K4_THREADS), dyn, stream, d_codes, d_off, n, st5, (int32_t)gap_open, (int32_t)gap_ext,
+                         row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, ld_score, nt, T8, d_bnd, bnd_stride, s1cap);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_bnd);
+    if (e != hipSuccess) return fail(DA_ERR_HIP, "k_nw_xlong failed: %s", hipGetErrorString(e));
+    return DA_OK;
+  }
   if (kind == DA_OUT_COMPACT && max_len > 127)
     return fail(DA_ERR_UNSUPPORTED, "uint16 NW output needs alignment length <= 255 (use the float64 or 32-bit packed kind)");
   // fast path: scores fit the score field of the combined key (see nw_row_ck / CKBits)

@@ -211,6 +211,9 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
 int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues,
                      uint8_t *d_codes, int32_t *d_bad, void *stream);
 
+/* Sequence lengths: <= 64 residues run one lane per pair (k_nw_short), 65..1024 one wavefront per pair (k_nw_long),
+ * 1025..32767 the same sweep in column blocks of 1024 with the block boundary spilled to HBM (k_nw_xlong; float64 / 32-bit
+ * packed output; synchronises the stream); longer ones fail with DA_ERR_UNSUPPORTED (16-bit alignment length). */
 /* K3: all-pairs NW identity.  Same row-block / symmetric / ld conventions as
  * da_dev_mh_compare.  d_codes from da_dev_nw_encode.  kind: double ratio or
  * uint16 (matches<<8|len).  d_score (int32, same shape, ld_score) may be NULL.

@@ -337,10 +337,35 @@ def test_nw_mid_length_lane_per_pair(da, lengths):
     assert_same_f64(da.similarityNW(seqs), want)
 
 
+@pytest.mark.parametrize("lengths", [(1025, 1024, 1027, 40, 0), (1500, 2500, 2049, 2048, 1, 300), (3100, 2047, 1024, 3073)])
+def test_nw_sequences_beyond_1024_residues(da, lengths):
+    """k_nw_xlong: column blocks of 1024 with the block boundary spilled to HBM (the reference is O(m n) for any length,
+    src/pairwiseSeqAlign.cpp:216-219): block edges exactly at / next to multiples of 1024, ragged partners, both
+    directions (long row / short column and the reverse), (matches, length, score) and the float64 matrix vs the oracle"""
+    rng = np.random.RandomState(sum(lengths))
+    seqs = _rand_seqs(rng, lengths, "ARNDCQEGHILKMFPSTWYV")
+    seqs.append(seqs[0])                                  # exact duplicate of a long one
+    mutated = list(seqs[1])
+    for k in range(0, len(mutated), 11):
+        mutated[k] = "W"
+    del mutated[500:517]                                  # a deletion -> long gap
+    seqs.append("".join(mutated))
+    rc, omt, oln, osc, _ = O.nw_rows(seqs)
+    assert rc == 0
+    mt, ln, sc = da.nw_pairs(seqs)
+    assert np.array_equal(mt, omt) and np.array_equal(ln, oln) and np.array_equal(sc, osc)
+    rc, want, _ = O.similarity_nw(seqs)
+    assert_same_f64(da.similarityNW(seqs), want)
+    mt2, ln2, sc2 = da.nw_pairs(seqs, "BLOSUM45", 3, 1, row_begin=1, row_end=len(seqs) - 1)       # row-block path, other penalties
+    rc, omt2, oln2, osc2, _ = O.nw_rows(seqs, 1, len(seqs) - 1, "BLOSUM45", 3, 1)
+    assert np.array_equal(mt2, omt2) and np.array_equal(ln2, oln2) and np.array_equal(sc2, osc2)
+
+
 def test_nw_too_long_sequences_fail_loudly(da):
+    """the alignment length travels in 16 bits: m + n <= 65535, i.e. sequences up to 32767 residues"""
     with pytest.raises(da.DynaAlignError) as ei:
-        da.similarityNW(["A" * 1025, "C" * 10])
-    assert ei.value.code == 10 and "1024" in str(ei.value)
+        da.similarityNW(["A" * 32768, "C" * 10])
+    assert ei.value.code == 10 and "32767" in str(ei.value)
 
 
 # ---------------------------------------------------------------- BASELINE sizes (properties)
