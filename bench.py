@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=100000, help="number of peptides (default: the 100k headline set)")
+    ap.add_argument("--n", type=int, default=int(os.environ.get("DYNAALIGN_BENCH_N", "100000")),
+                    help="number of peptides (default: the 100k headline set; DYNAALIGN_BENCH_N sets it where a launcher eats --n)")
     ap.add_argument("--workload", default="h3n2like", choices=["h3n2like", "uniform"])
     ap.add_argument("--no-nw", action="store_true", help="skip the similarityNW measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
@@ -160,10 +161,17 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    # DYNAALIGN_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (the ranks share
+    # the visible devices, the exchange goes through the host) -- never a measurement
+    backend = os.environ.get("DYNAALIGN_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % ndev if backend != "nccl" else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     import dynaalign_amd as da
     from dynaalign_amd import _capi, device, sharding, synth
@@ -281,7 +289,7 @@ def main():
         "metric": "sequence-pairs/sec (MinHash k=4 n_hash=500; NW BLOSUM62) at 1/2/4/8 MI355X",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u32", "data": "synthetic",
+        "dtype": "u32", "data": "synthetic" if os.environ.get("DYNAALIGN_BENCH_BACKEND", "nccl") == "nccl" else "synthetic; REHEARSAL over %s, not a measurement" % os.environ["DYNAALIGN_BENCH_BACKEND"],
         "boundary": "T_k: kernels only, packed residues and the dense f64 result resident in HBM" if world == 1 else
                     "T_g: kernels + one RCCL all-gather + finalize, dense f64 result resident in every rank's HBM",
         "config": {"workload": "similarityMH k=4 n_hash=500 on %d %s 20-mers (hash seed 12345), dense f64 NxN in HBM"

@@ -1311,6 +1311,45 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   return DA_OK;
 }
 
+// Store phase shared by the three "64 x 64 uint16 tile in LDS -> float64 output, direct + mirrored" kernels below.  Interior
+// off-diagonal tiles of an even-ld, 16-byte aligned matrix take 16-byte streaming stores (two adjacent doubles per lane: a
+// wave-instruction covers two 512-byte row pieces; 8-byte stores run at 0.5-0.7x the rate, MI355X_MICROARCH.md); everything
+// else (diagonal tiles, borders, odd ld) the bounds-checked scalar path.
+template <typename WIDEN>
+__device__ __forceinline__ void store_tile_f64(const uint16_t (&t)[64][66], WIDEN widen, double *__restrict__ out, int64_t ld, int n,
+                                                int i0, int j0) {
+  constexpr int FT = 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4 (scalar path)
+  const bool fast = i0 != j0 && i0 + FT <= n && j0 + FT <= n && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                    ((i0 | j0) & 1) == 0;
+  if (fast) {
+    const int k2 = 2 * (threadIdx.x & 31), rg = threadIdx.x >> 5;      // column pair, row group 0..7
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int r = rg + 8 * p;
+      nt_store2(out + (int64_t)(i0 + r) * ld + j0 + k2, widen(t[r][k2]), widen(t[r][k2 + 1]));          // upper part as computed
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int r = rg + 8 * p;
+      nt_store2(out + (int64_t)(j0 + r) * ld + i0 + k2, widen(t[k2][r]), widen(t[k2 + 1][r]));          // out[j][i] = upper(i, j)
+    }
+    return;
+  }
+  const int j = j0 + tx;
+  double *o = out + (int64_t)i0 * ld + j;
+  for (int r = ty; r < FT; r += 4) {
+    const int i = i0 + r;
+    if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part as computed
+  }
+  const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
+  double *om = out + (int64_t)j0 * ld + im;
+  for (int r = ty; r < FT; r += 4) {
+    const int jm = j0 + r;
+    if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
+  }
+}
+
 // Gathered shards -> final matrix.  G holds, for every rank p, its folded local block
 // (ShardGeom); out[i][j] = widen(G[entry of (min(i,j), max(i,j))]).  One workgroup per 64 x 64
 // tile on or above the diagonal, enumerated like the compare kernel's tiles (bands of 8 tile rows,
@@ -1359,17 +1398,7 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
     if (i < n && j < n && j >= i) t[r][tx] = src[(int64_t)r * ld_g];
   }
   __syncthreads();
-  double *o = out + (int64_t)i0 * ld + j;
-  for (int r = ty; r < FT; r += 4) {
-    const int i = i0 + r;
-    if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part as computed
-  }
-  const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
-  double *om = out + (int64_t)j0 * ld + im;
-  for (int r = ty; r < FT; r += 4) {
-    const int jm = j0 + r;
-    if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
-  }
+  store_tile_f64(t, widen, out, ld, n, i0, j0);
 }
 
 // Dense symmetric n x n result from the square table D of UNIQUE sequences (NW dedupe, nw_kernels.hip):
@@ -1407,18 +1436,7 @@ __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restric
   }
   __syncthreads();
   if (F64) {
-    double *out = reinterpret_cast<double *>(out_v);
-    double *o = out + (int64_t)i0 * ld + j;
-    for (int r = ty; r < FT; r += 4) {
-      const int i = i0 + r;
-      if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part
-    }
-    const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
-    double *om = out + (int64_t)j0 * ld + im;
-    for (int r = ty; r < FT; r += 4) {
-      const int jm = j0 + r;
-      if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
-    }
+    store_tile_f64(t, widen, reinterpret_cast<double *>(out_v), ld, n, i0, j0);
   } else {
     uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
     uint16_t *o = out + (int64_t)i0 * ld + j;
@@ -1542,17 +1560,7 @@ __global__ __launch_bounds__(256) void k_finalize_packed(const uint8_t *__restri
     }
   }
   __syncthreads();
-  double *o = out + (int64_t)i0 * ld + j;
-  for (int r = ty; r < FT; r += 4) {
-    const int i = i0 + r;
-    if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part as computed
-  }
-  const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
-  double *om = out + (int64_t)j0 * ld + im;
-  for (int r = ty; r < FT; r += 4) {
-    const int jm = j0 + r;
-    if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
-  }
+  store_tile_f64(t, widen, out, ld, n, i0, j0);
 }
 
 int64_t shard_packed_bytes(const ShardGeom &g, int value_bits) {
