@@ -327,7 +327,7 @@ def main():
             # ordered square and the N x N result is an index expansion (da_nw_last_route: unique count + phase times)
             route = device.nw_last_route()
             nw_obj["route"] = dict(route, note="dedup: DP on the unique strings (ordered square) + expansion; direct: one lane per pair of the input")
-            nw_kernel = "k_nw_short<20, true>"
+            nw_kernel = "k_nw_short<20, true, %s>" % ("true" if route["dedup"] else "false")    # <NMAX, combined key, ordered mode>
             pm = pmc_kernel(nw_kernel, n)
             bytes_nw = n * L + n * n * 8
             t_dp = route["dp_ms"] * 1e-3 if route["dp_ms"] > 0 else t_nw

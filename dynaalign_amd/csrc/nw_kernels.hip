@@ -173,7 +173,7 @@ __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMA
   }
 }
 
-template <int NMAX, bool CK>
+template <int NMAX, bool CK, bool ORD>
 __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   // ord_first != NULL: ORDERED mode on a table of UNIQUE sequences (nw_dedup below): element (p, q) of the full square is
   // calc(U_p, U_q) with U_p as sequence1 whatever the order of p and q, computed only where some pair i < j of the original
   // input maps to it: first(p) < last(q) (or p == q).
-  const bool ordered = ord_first != nullptr;
+  constexpr bool ordered = ORD;               // (a template parameter: the two modes show up as two kernels in profiles)
   const bool f64_out = kind == DA_OUT_F64;
   __shared__ __attribute__((aligned(16))) Cell tab[CK ? 1 : 24 * 24];
   __shared__ int32_t tabk[CK ? 24 * 24 : 1];
@@ -1072,13 +1072,18 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
   if (ntiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "pair space too large for one launch");
   dim3 grid((unsigned)ntiles), block(K3_THREADS);
-#define DA_K3(NM)                                                                                   \
-  if (ck) hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
-                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast); \
-  else hipLaunchKernelGGL((k_nw_short<NM, false>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
-                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast)
+#define DA_K3_ARGS d_codes, d_off, n, st, (int32_t)gap_open, (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, \
+                   d_score, ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast
+#define DA_K3(NM)                                                                                                     \
+  do {                                                                                                                \
+    if (ord_first) {                                                                                                  \
+      if (ck) hipLaunchKernelGGL((k_nw_short<NM, true, true>), grid, block, 0, stream, DA_K3_ARGS);                   \
+      else hipLaunchKernelGGL((k_nw_short<NM, false, true>), grid, block, 0, stream, DA_K3_ARGS);                     \
+    } else {                                                                                                          \
+      if (ck) hipLaunchKernelGGL((k_nw_short<NM, true, false>), grid, block, 0, stream, DA_K3_ARGS);                  \
+      else hipLaunchKernelGGL((k_nw_short<NM, false, false>), grid, block, 0, stream, DA_K3_ARGS);                    \
+    }                                                                                                                 \
+  } while (0)
   if (max_len <= 8) DA_K3(8);
   else if (max_len <= 12) DA_K3(12);
   else if (max_len <= 16) DA_K3(16);
@@ -1086,14 +1091,16 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   else if (max_len <= 24) DA_K3(24);
   else if (max_len <= 32) DA_K3(32);
   else {
-#define DA_K3CK(NM)                                                                                    \
-  hipLaunchKernelGGL((k_nw_short<NM, true>), grid, block, 0, stream, d_codes, d_off, n, st, (int32_t)gap_open, \
-                     (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, d_score, \
-                     ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast)
+#define DA_K3CK(NM)                                                                                                   \
+  do {                                                                                                                \
+    if (ord_first) hipLaunchKernelGGL((k_nw_short<NM, true, true>), grid, block, 0, stream, DA_K3_ARGS);              \
+    else hipLaunchKernelGGL((k_nw_short<NM, true, false>), grid, block, 0, stream, DA_K3_ARGS);                       \
+  } while (0)
     if (max_len <= 48) DA_K3CK(48); else DA_K3CK(64);
 #undef DA_K3CK
   }
 #undef DA_K3
+#undef DA_K3_ARGS
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
