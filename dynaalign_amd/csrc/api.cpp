@@ -3,6 +3,8 @@
 // Host-side marshalling only: argument validation with the reference's error
 // order and message texts, packing, H2D/D2H, and kernel launches.  There is
 // deliberately NO CPU implementation of the hot path in this library.
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -12,6 +14,7 @@
 #include <memory>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <random>
 #include <thread>
@@ -185,12 +188,12 @@ class CopyPool {
     cv_.notify_all();
     for (auto &t : th_) t.join();
   }
-  // dst[0, len) <- src[0, len), split over the workers + the calling thread; returns when all parts are done
-  void copy(char *dst, const char *src, size_t len) {
+  // fn(b, e) over [0, len) split into one piece per worker + the calling thread; returns when all pieces are done
+  void run_split(size_t len, const std::function<void(size_t, size_t)> &fn) {
     const size_t parts = th_.size() + 1, part = (len + parts - 1) / parts;
-    { std::lock_guard<std::mutex> g(m_); dst_ = dst; src_ = src; len_ = len; part_ = part; pending_ = (int)th_.size(); ++gen_; }
+    { std::lock_guard<std::mutex> g(m_); fn_ = &fn; len_ = len; part_ = part; pending_ = (int)th_.size(); ++gen_; }
     cv_.notify_all();
-    memcpy(dst, src, std::min(part, len));
+    fn(0, std::min(part, len));
     std::unique_lock<std::mutex> g(m_);
     done_.wait(g, [this]() { return pending_ == 0; });
   }
@@ -203,10 +206,11 @@ class CopyPool {
       cv_.wait(g, [&]() { return gen_ != seen; });
       seen = gen_;
       if (stop_) return;
-      char *d = dst_; const char *s = src_; const size_t len = len_, part = part_;
+      const std::function<void(size_t, size_t)> *fn = fn_;
+      const size_t len = len_, part = part_;
       g.unlock();
       const size_t b = (size_t)(w + 1) * part;
-      if (b < len) memcpy(d + b, s + b, std::min(part, len - b));
+      if (b < len) (*fn)(b, std::min(len, b + part));
       g.lock();
       if (--pending_ == 0) done_.notify_one();
     }
@@ -216,17 +220,43 @@ class CopyPool {
   std::condition_variable cv_, done_;
   uint64_t gen_ = 0;
   bool stop_ = false;
-  char *dst_ = nullptr; const char *src_ = nullptr;
+  const std::function<void(size_t, size_t)> *fn_ = nullptr;
   size_t len_ = 0, part_ = 0;
   int pending_ = 0;
 };
 
-int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
+// dst[i] = table[src[i]] with streaming stores (the destination is written once: no read-for-ownership traffic)
+void widen_u16_to_f64(double *dst, const uint16_t *src, size_t b, size_t e, const double *table) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  size_t i = b;
+  if (i < e && (reinterpret_cast<uintptr_t>(dst + i) & 15)) { dst[i] = table[src[i]]; ++i; }
+  for (; i + 2 <= e; i += 2) {
+    const v2d v = {table[src[i]], table[src[i + 1]]};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(dst + i));
+  }
+  if (i < e) dst[i] = table[src[i]];
+}
+
+// Device -> caller-owned pageable host memory through the pinned ring.  With `table` the device buffer holds uint16 codes and
+// the HOST widens them while copying: dst (double) [i] = table[code[i]] -- a quarter of the bytes cross PCIe (the 80 GB float64
+// result of N = 100k took 1.48 s at 54 GB/s; as codes it is 20 GB), and the divide behind every table entry is the same IEEE
+// operation on the host as on the device (src/minHash.cpp:174, src/pairwiseSeqAlign.cpp:311).
+int d2h_pipelined(void *dst, const void *d_src, size_t bytes, const double *table = nullptr) {
   constexpr size_t CHUNK = (size_t)64 << 20;
   constexpr int RING = 4, MAX_WORKERS = 32;
-  int WORKERS = 8;                       // host threads per chunk (first-touch page faults of the destination parallelise)
+  int WORKERS = table ? 16 : 8;          // host threads per chunk (first-touch page faults of the destination parallelise)
   if (const char *e = getenv("DYNAALIGN_D2H_THREADS")) WORKERS = std::max(1, std::min(MAX_WORKERS, atoi(e)));
-  if (bytes <= CHUNK || getenv("DYNAALIGN_PLAIN_D2H")) {
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t cs;
+    int avail = (sched_getaffinity(0, sizeof cs, &cs) == 0) ? CPU_COUNT(&cs) : (int)hw;
+    if (avail > 0 && WORKERS > avail) WORKERS = avail;
+  }
+  if (bytes <= CHUNK && !table) {
+    DA_HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return DA_OK;
+  }
+  if (getenv("DYNAALIGN_PLAIN_D2H") && !table) {
     DA_HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return DA_OK;
   }
@@ -260,7 +290,15 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes) {
       if (c >= RING - 1) {
         const size_t done = c - (RING - 1), off = done * CHUNK, len = std::min(CHUNK, bytes - off);
         if (!check(hipEventSynchronize(ring[done % RING].ev), "hipEventSynchronize")) break;
-        pool.copy(static_cast<char *>(dst) + off, static_cast<const char *>(ring[done % RING].pin), len);
+        const char *src = static_cast<const char *>(ring[done % RING].pin);
+        if (table) {
+          double *d = static_cast<double *>(dst) + off / 2;                 // `bytes` counts the uint16 source
+          const uint16_t *s16 = reinterpret_cast<const uint16_t *>(src);
+          pool.run_split(len / 2, [=](size_t b, size_t e) { widen_u16_to_f64(d, s16, b, e, table); });
+        } else {
+          char *d = static_cast<char *>(dst) + off;
+          pool.run_split(len, [=](size_t b, size_t e) { memcpy(d + b, src + b, e - b); });
+        }
       }
     }
   }
@@ -1058,6 +1096,19 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
     DA_HIP_TRY(hipStreamSynchronize(nullptr));   // the workspace is released here
   }
   tr.mark("signatures + codes");
+  if (kind == DA_OUT_F64 && row_begin == 0 && row_end == n && rows_per_block(n, sizeof(uint16_t)) >= n && !getenv("DYNAALIGN_NO_HOST_WIDEN")) {
+    // the float64 matrix for a HOST caller: counts (uint16) leave the device, a quarter of the bytes over PCIe, and the host
+    // widens them while copying -- count / n_hash is the same IEEE divide here as on the device (src/minHash.cpp:174)
+    DevBuf dcnt;
+    if ((rc = dcnt.alloc((size_t)n * (size_t)n * sizeof(uint16_t))) != DA_OK) return rc;
+    if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, DA_OUT_COMPACT, dcnt.p, n, nullptr, bits)) != DA_OK) return rc;
+    tr.mark("compare (uint16 counts)");
+    std::vector<double> table((size_t)n_hash + 1);
+    for (int c = 0; c <= n_hash; ++c) table[(size_t)c] = (double)c / (double)n_hash;
+    if ((rc = d2h_pipelined(out, dcnt.p, (size_t)n * (size_t)n * sizeof(uint16_t), table.data())) != DA_OK) return rc;
+    tr.mark("device -> host + widen");
+    return DA_OK;
+  }
   const size_t esz = kind == DA_OUT_F64 ? sizeof(double) : sizeof(uint16_t);
   const int64_t rows_total = row_end - row_begin;
   const int64_t blk = rows_per_block(n, esz);
@@ -1144,6 +1195,22 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
     return rc;
 
   const int64_t rows_total = row_end - row_begin;
+  if (out_f64 && row_begin == 0 && row_end == n && max_len <= 127 && rows_per_block(n, sizeof(uint16_t)) >= n &&
+      !getenv("DYNAALIGN_NO_HOST_WIDEN")) {
+    // as for similarityMH: the (matches << 8 | length) codes cross PCIe and the host divides (src/pairwiseSeqAlign.cpp:311)
+    DevBuf dcode;
+    if ((rc = dcode.alloc((size_t)n * (size_t)n * sizeof(uint16_t))) != DA_OK) return rc;
+    if ((rc = nw_full_symmetric(codes.as<uint8_t>(), in.off.as<int64_t>(), n, total, max_len, mid, gap_open, gap_ext, DA_OUT_COMPACT,
+                                dcode.p, n, nullptr)) != DA_OK) return rc;
+    std::vector<double> table(65536);
+    const uint64_t nan_bits = 0xFFF8000000000000ULL;        // 0/0 as the reference's x86 host produces it
+    for (uint32_t v = 0; v < 65536; ++v) {
+      const uint32_t ln = v & 255u;
+      if (ln == 0) memcpy(&table[v], &nan_bits, 8);
+      else table[v] = (double)(v >> 8) / (double)ln;
+    }
+    return d2h_pipelined(out_f64, dcode.p, (size_t)n * (size_t)n * sizeof(uint16_t), table.data());
+  }
   if (out_f64) {
     const int64_t blk = rows_per_block(n, sizeof(double));
     const bool whole = (row_begin == 0 && row_end == n && blk >= n);

@@ -462,3 +462,24 @@ def test_100k_headline_workload_properties(da):
         rc, mt, ln, _, _ = O.nw_rows(seqs, r0, r0 + 4)
         assert rc == 0
         assert_same_f64(out[r0:r0 + 4].cpu().numpy(), mt / ln.astype(np.float64))
+
+
+def test_host_widening_and_device_float64_routes_agree(da, monkeypatch):
+    """host-pointer float64 results: by default the device hands over uint16 codes and the HOST widens while copying (a quarter
+    of the PCIe bytes; same IEEE divide); DYNAALIGN_NO_HOST_WIDEN=1 copies the device's float64 matrix.  Same bits, including
+    the NaN of empty-vs-empty NW pairs, on an input large enough for the pinned-ring pipeline (> 64 MiB of codes)."""
+    from dynaalign_amd import synth
+    seqs = synth.to_strings(*synth.h3n2_like(6000, 20))
+    seqs[17] = ""
+    seqs[4321] = ""
+    a = np.asarray(da.similarityMH(seqs, 4, 300, seed=3))
+    w = np.asarray(da.similarityNW(seqs))
+    monkeypatch.setenv("DYNAALIGN_NO_HOST_WIDEN", "1")
+    b = np.asarray(da.similarityMH(seqs, 4, 300, seed=3))
+    v = np.asarray(da.similarityNW(seqs))
+    assert_same_f64(a, b)
+    assert_same_f64(w, v)
+    assert np.isnan(w[17, 4321]) and np.isnan(w[17, 17]) and w[17, 0] == 0.0
+    rc, mt, ln, _, _ = O.nw_rows(seqs, 17, 18)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert_same_f64(w[17], mt[0].astype(np.float64) / ln[0].astype(np.float64))
