@@ -9,6 +9,7 @@
 // work; no MFMA (an equality count is not a contraction).
 #include "da_common.hpp"
 
+#include <atomic>
 #include <type_traits>
 
 namespace da {
@@ -1259,9 +1260,9 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   // the following tile's stage loop).
   const bool p12 = a12 && n_hash > K2_GROUP && (kind != DA_OUT_F64 || n_hash < K2_P12_TABLE) && getenv("DYNAALIGN_K2_PERSIST");
   if (p12) {
-    static int occ_cache[2] = {0, 0}, cus_cache = 0;              // resident workgroups per CU (4 expected), CUs of the device
-    const int ki = kind == DA_OUT_F64 ? 0 : 1;
-    if (!occ_cache[ki]) {
+    static std::atomic<int> occ_cache[2], cus_cache;              // resident workgroups per CU (4 expected), CUs of the device;
+    const int ki = kind == DA_OUT_F64 ? 0 : 1;                    // (atomics: the multi-device entry points launch from several host threads)
+    if (!occ_cache[ki].load()) {
       int occ = 0;
       if (ki == 0) DA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mh_compare_p12<true>, K2_THREADS, 0));
       else DA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mh_compare_p12<false>, K2_THREADS, 0));
@@ -1270,12 +1271,12 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
       DA_HIP_TRY(hipGetDevice(&dev));
       DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
       if (const char *e = getenv("DYNAALIGN_K2_WG_PER_CU")) occ = atoi(e);
-      occ_cache[ki] = occ > 0 ? occ : 1;
-      cus_cache = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      cus_cache.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+      occ_cache[ki].store(occ > 0 ? occ : 1);
       if (getenv("DYNAALIGN_TRACE"))
-        fprintf(stderr, "[dynaalign] k_mh_compare_p12<%s>: %d resident workgroups per CU, %d CUs\n", ki == 0 ? "f64" : "u16", occ_cache[ki], cus_cache);
+        fprintf(stderr, "[dynaalign] k_mh_compare_p12<%s>: %d resident workgroups per CU, %d CUs\n", ki == 0 ? "f64" : "u16", occ_cache[ki].load(), cus_cache.load());
     }
-    int wg_per_xcd = occ_cache[ki] * ((cus_cache + 7) / 8);
+    int wg_per_xcd = occ_cache[ki].load() * ((cus_cache.load() + 7) / 8);
     if ((int64_t)wg_per_xcd > per_xcd) wg_per_xcd = (int)(per_xcd > 0 ? per_xcd : 1);
     const dim3 pgrid((unsigned)(8 * wg_per_xcd));
     if (kind == DA_OUT_F64)

@@ -208,3 +208,54 @@ def test_default_seed_is_one_hash_family_for_all_ranks(built):
     assert s0 == s1 and fam0 == fam1 and len(fam0) == 16
     assert e0 == e1 == 1000
     assert 0 <= s0 < 2 ** 32
+
+
+def _nw_edges_rank_main(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dynaalign_amd  # noqa: F401  (host-side quantile lives in the library)
+        seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+        plan = sharding.Plan(n, rank, world, sharding.NW_TILE)
+        values = sharding.nw_code_values(20)
+        code = {}
+        for i in plan.my_rows():
+            rc, mt, ln, _, _ = O.nw_rows(seqs, i, i + 1)
+            for j in range(i, n):
+                code[(i, j)] = (int(mt[0][j]) << 8) | int(ln[0][j])
+        hist = np.bincount([c for (i, j), c in code.items() if j > i], minlength=len(values)).astype(np.int64)
+
+        def extract(keep, capacity):
+            e = sorted((i, j, c) for (i, j), c in code.items() if keep[c] or i == j)
+            assert len(e) == capacity
+            return [x[0] for x in e], [x[1] for x in e], [x[2] for x in e], len(e)
+
+        thr, ei, ej, ev, c, cap = sharding.edges_from_histograms(plan, torch.from_numpy(hist), 0, 0.8,
+                                                                 lambda t: dist.all_reduce(t), extract, values=values)
+        q.put((rank, thr, [(a, b, float(values[v])) for a, b, v in zip(ei, ej, ev)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_nw_edges_all_reduce_matches_dense_threshold(built):
+    """the NW twin: bins are alignment codes whose VALUES (matches / length) are not in bin order -- the quantile runs over
+    the values; world_size 2 over gloo, one all-reduce of the code histogram, disjoint local edge lists"""
+    from test_threshold_edges import reference_edges
+    world, n = 2, 260
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nw_edges_rank_main, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+    rc, M, _ = O.similarity_nw(seqs)
+    thr_w, iw, jw, ww = reference_edges(M, 0.8)
+    got = sorted(e for _, _, edges in results for e in edges)
+    assert {thr for _, thr, _ in results} == {thr_w}
+    assert [(a, b) for a, b, _ in got] == list(zip(iw.tolist(), jw.tolist()))
+    assert [w for _, _, w in got] == ww.tolist()
