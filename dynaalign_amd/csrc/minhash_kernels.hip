@@ -1316,36 +1316,33 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
 // off-diagonal tiles of an even-ld, 16-byte aligned matrix take 16-byte streaming stores (two adjacent doubles per lane: a
 // wave-instruction covers two 512-byte row pieces; 8-byte stores run at 0.5-0.7x the rate, MI355X_MICROARCH.md); everything
 // else (diagonal tiles, borders, odd ld) the bounds-checked scalar path.
-template <typename WIDEN>
-__device__ __forceinline__ void store_tile_f64(const uint16_t (&t)[64][66], WIDEN widen, double *__restrict__ out, int64_t ld, int n,
+template <int FT, typename WIDEN>
+__device__ __forceinline__ void store_tile_f64(const uint16_t (&t)[FT][FT + 2], WIDEN widen, double *__restrict__ out, int64_t ld, int n,
                                                 int i0, int j0) {
-  constexpr int FT = 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4 (scalar path)
+  const int tx = threadIdx.x & (FT - 1), ty = threadIdx.x / FT;  // FT x (256 / FT) (scalar path)
   const bool fast = i0 != j0 && i0 + FT <= n && j0 + FT <= n && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                     ((i0 | j0) & 1) == 0;
   if (fast) {
-    const int k2 = 2 * (threadIdx.x & 31), rg = threadIdx.x >> 5;      // column pair, row group 0..7
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int r = rg + 8 * p;
+    constexpr int PAIRS = FT / 2, RG = 256 / PAIRS;                     // column pairs per row; row groups
+    const int k2 = 2 * (threadIdx.x % PAIRS), rg = threadIdx.x / PAIRS;
+#pragma unroll 8
+    for (int r = rg; r < FT; r += RG)
       nt_store2(out + (int64_t)(i0 + r) * ld + j0 + k2, widen(t[r][k2]), widen(t[r][k2 + 1]));          // upper part as computed
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int r = rg + 8 * p;
+#pragma unroll 8
+    for (int r = rg; r < FT; r += RG)
       nt_store2(out + (int64_t)(j0 + r) * ld + i0 + k2, widen(t[k2][r]), widen(t[k2 + 1][r]));          // out[j][i] = upper(i, j)
-    }
     return;
   }
+  constexpr int RS = 256 / FT;
   const int j = j0 + tx;
   double *o = out + (int64_t)i0 * ld + j;
-  for (int r = ty; r < FT; r += 4) {
+  for (int r = ty; r < FT; r += RS) {
     const int i = i0 + r;
     if (i < n && j < n && j >= i) o[(int64_t)r * ld] = widen(t[r][tx]);  // upper part as computed
   }
   const int im = i0 + tx;                                                // out[j][i] = upper(i, j)
   double *om = out + (int64_t)j0 * ld + im;
-  for (int r = ty; r < FT; r += 4) {
+  for (int r = ty; r < FT; r += RS) {
     const int jm = j0 + r;
     if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = widen(t[tx][r]);
   }
@@ -1399,7 +1396,7 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
     if (i < n && j < n && j >= i) t[r][tx] = src[(int64_t)r * ld_g];
   }
   __syncthreads();
-  store_tile_f64(t, widen, out, ld, n, i0, j0);
+  store_tile_f64<64>(t, widen, out, ld, n, i0, j0);
 }
 
 // Dense symmetric n x n result from the square table D of UNIQUE sequences (NW dedupe, nw_kernels.hip):
@@ -1407,11 +1404,10 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
 // 64 x 64 output tiles on or above the diagonal in the banded XCD order of k_finalize_sharded, gathered through LDS so that
 // the mirrored half is written as row pieces too.  Single-copy strings are numbered in input order, so most of a row's
 // gather hits consecutive table columns; the multi-copy ones sit in the first few KiB of every table row.
-template <bool F64, bool IS_NW>
+template <bool F64, bool IS_NW, int FT>
 __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                        int n, int n_hash, void *__restrict__ out_v, int64_t ld, int TB,
                                                        int64_t ntiles, int64_t per_xcd) {
-  constexpr int FT = 64;
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ int32_t ur[FT], uc[FT];
   const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -1419,9 +1415,12 @@ __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restric
   const TileId tt = decode_tile(L, TB, TB, true);
   if (!tt.valid) return;
   const int i0 = tt.ti * FT, j0 = tt.tj * FT;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-  if (threadIdx.x < 64) ur[threadIdx.x] = (i0 + (int)threadIdx.x < n) ? uidx[i0 + threadIdx.x] : 0;
-  else if (threadIdx.x < 128) uc[threadIdx.x - 64] = (j0 + (int)threadIdx.x - 64 < n) ? uidx[j0 + threadIdx.x - 64] : 0;
+  constexpr int RS = 256 / FT;
+  const int tx = threadIdx.x & (FT - 1), ty = threadIdx.x / FT;  // FT x (256 / FT)
+  for (int q = threadIdx.x; q < 2 * FT; q += 256) {
+    if (q < FT) ur[q] = (i0 + q < n) ? uidx[i0 + q] : 0;
+    else uc[q - FT] = (j0 + q - FT < n) ? uidx[j0 + q - FT] : 0;
+  }
   __syncthreads();
   auto widen = [&](uint32_t v) -> double {
     if (!IS_NW) return (double)v / (double)n_hash;
@@ -1431,23 +1430,23 @@ __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restric
   };
   const int j = j0 + tx;
   const int32_t cj = uc[tx];
-  for (int r = ty; r < FT; r += 4) {
+  for (int r = ty; r < FT; r += RS) {
     const int i = i0 + r;
     if (i < n && j < n && j >= i) t[r][tx] = D[(int64_t)ur[r] * ld_d + cj];
   }
   __syncthreads();
   if (F64) {
-    store_tile_f64(t, widen, reinterpret_cast<double *>(out_v), ld, n, i0, j0);
+    store_tile_f64<FT>(t, widen, reinterpret_cast<double *>(out_v), ld, n, i0, j0);
   } else {
     uint16_t *out = reinterpret_cast<uint16_t *>(out_v);
     uint16_t *o = out + (int64_t)i0 * ld + j;
-    for (int r = ty; r < FT; r += 4) {
+    for (int r = ty; r < FT; r += RS) {
       const int i = i0 + r;
       if (i < n && j < n && j >= i) o[(int64_t)r * ld] = t[r][tx];
     }
     const int im = i0 + tx;
     uint16_t *om = out + (int64_t)j0 * ld + im;
-    for (int r = ty; r < FT; r += 4) {
+    for (int r = ty; r < FT; r += RS) {
       const int jm = j0 + r;
       if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = t[tx][r];
     }
@@ -1459,14 +1458,20 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   if (n <= 0) return DA_OK;
   if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "expand: matrix too large");
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "expand: bad output kind");
-  const int TB = (int)ceil_div(n, 64);
+  const int ft = getenv("DYNAALIGN_EXPAND_TILE") ? atoi(getenv("DYNAALIGN_EXPAND_TILE")) : 64;   // experiment knob: 64 or 128
+  const int TB = (int)ceil_div(n, ft == 128 ? 128 : 64);
   const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   const int64_t per_xcd = ceil_div(tiles, 8);
   const dim3 grid((unsigned)(per_xcd * 8));
-#define DA_EXP(F, W) hipLaunchKernelGGL((k_expand_unique<F, W>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd)
-  if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true); else DA_EXP(true, false); }
-  else { if (is_nw) DA_EXP(false, true); else DA_EXP(false, false); }
+#define DA_EXP(F, W, T) hipLaunchKernelGGL((k_expand_unique<F, W, T>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd)
+  if (ft == 128) {
+    if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 128); else DA_EXP(true, false, 128); }
+    else { if (is_nw) DA_EXP(false, true, 128); else DA_EXP(false, false, 128); }
+  } else {
+    if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 64); else DA_EXP(true, false, 64); }
+    else { if (is_nw) DA_EXP(false, true, 64); else DA_EXP(false, false, 64); }
+  }
 #undef DA_EXP
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
@@ -1561,7 +1566,7 @@ __global__ __launch_bounds__(256) void k_finalize_packed(const uint8_t *__restri
     }
   }
   __syncthreads();
-  store_tile_f64(t, widen, out, ld, n, i0, j0);
+  store_tile_f64<64>(t, widen, out, ld, n, i0, j0);
 }
 
 int64_t shard_packed_bytes(const ShardGeom &g, int value_bits) {
