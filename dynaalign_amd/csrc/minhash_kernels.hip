@@ -575,6 +575,9 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a16(const uint32_t
 #ifndef K2_LOOP_INC_P
 #define K2_LOOP_INC_P "k2_loop_p12p.inc"
 #endif
+#ifdef K2_DYNAMIC   // experiment: tile ids handed out by a per-XCD atomic counter (a sliding window like the hardware dispatcher's)
+__device__ unsigned int g_k2_next[8];
+#endif
 constexpr int K2_P12_TABLE = 512;
 template <bool F64>
 __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
@@ -624,7 +627,28 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
   for (int w = 0; w < ((slot ^ (slot >> 5)) & 3) * K2_STAGGER; ++w) __builtin_amdgcn_s_sleep(127);
 #endif
   TileId cur, nxt;
+#ifdef K2_DYNAMIC
+  __shared__ unsigned int s_next[2];
+  int fetch_no = 0;
+  auto next_dyn = [&](TileId &t) -> int {
+    for (;;) {
+      if (tid == 0) s_next[fetch_no & 1] = atomicAdd(&g_k2_next[xcd], 1u);
+      __syncthreads();
+      const int Lq = (int)((int64_t)xcd * per_xcd) + (int)__builtin_amdgcn_readfirstlane(s_next[fetch_no & 1]);
+      ++fetch_no;
+      if (Lq >= lim) return lim;
+      int To = T;
+      asm volatile("" : "+s"(To));
+      t = decode_tile(Lq, To, To, true);
+      t.ti = __builtin_amdgcn_readfirstlane(t.ti);
+      t.tj = __builtin_amdgcn_readfirstlane(t.tj);
+      if (t.valid && a12_takes(t.ti, t.tj, n, ld, out_v, F64)) return Lq;
+    }
+  };
+  int L = next_dyn(cur);
+#else
   int L = next_taken((int)((int64_t)xcd * per_xcd) + slot, cur);
+#endif
   uint32_t flags = 1u, phase = 0u;                             // bit 0: first tile of this workgroup; ring slot of the tile's stage 0
 #ifdef DA_K2_TIMING
   int it_stamp = 0;
@@ -635,7 +659,11 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
 #endif
   while (L < lim) {
     K2P_STAMP(0);
+#ifdef K2_DYNAMIC
+    const int Ln = next_dyn(nxt);
+#else
     const int Ln = next_taken(L + wg_per_xcd, nxt);
+#endif
     if (Ln < lim) flags |= 2u;
     const uint64_t src = source_of(cur), src_n = source_of(nxt);
     const uint32_t sl = __builtin_amdgcn_readfirstlane((uint32_t)src), sh = __builtin_amdgcn_readfirstlane((uint32_t)(src >> 32));
@@ -1279,6 +1307,12 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
     int wg_per_xcd = occ_cache[ki].load() * ((cus_cache.load() + 7) / 8);
     if ((int64_t)wg_per_xcd > per_xcd) wg_per_xcd = (int)(per_xcd > 0 ? per_xcd : 1);
     const dim3 pgrid((unsigned)(8 * wg_per_xcd));
+#ifdef K2_DYNAMIC
+    {
+      static const unsigned int zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      DA_HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_k2_next), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, stream));
+    }
+#endif
     if (kind == DA_OUT_F64)
       hipLaunchKernelGGL(k_mh_compare_p12<true>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd);
     else
