@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full pass of similarityMH(k=4, n_hash=500) over the workload with the packed residues already
-resident in HBM: signature build (K1) + exact re-coding (K1b) + all-pairs compare (K2) producing the dense float64
+resident in HBM -- ONE C call, da_dev_similarity_mh: duplicate plan + signature build (K1) + exact re-coding (K1b) + all-pairs
+compare (K2) [+ index expansion when byte-identical sequences were collapsed] producing the dense float64
 N x N matrix in HBM (what the reference returns to R).  `value` is on that boundary -- T_k of SURVEY 8(d): kernels
 only, inputs and result resident in HBM.  With N > 1 ranks the pair space is row-sharded (cyclic tile rows), each
 rank's compact block is exchanged with ONE RCCL all-gather and mirrored / widened to the full float64 matrix on every
@@ -13,7 +14,9 @@ rank (T_g); total work is fixed, so `scaling` is "strong".
 
 Headline workload (BASELINE.json configs[3], the one the metric is quoted on): 100 000 h3n2-like 20-mers, MinHash
 k=4 n_hash=500, hash seed 12345.  The same JSON line also carries
-    roofline      the dominant kernel (K2): algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak, + the VALU bound
+    roofline      the dominant kernel of the timed step: algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak
+                  (k_expand_rows when the duplicate-collapsing route runs, with K2 on the unique rows beside it; K2 + its VALU bound otherwise)
+    direct        the same input with the route off (K2 on all N rows) and K2's roofline object
     nw            similarityNW BLOSUM62/10/4 on the same set (second half of the metric) with its own roofline object
     uniform       the other SURVEY 8(d) workload, S100k uniform (16 code planes instead of 12: k_mh_compare_a16)
     t_h           the host-pointer boundary (what R sees): da_similarity_mh / _nw into a pageable host matrix, PCIe-inclusive
@@ -205,15 +208,17 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
     if world == 1:
+        if a.plane_bits:
+            os.environ["DYNAALIGN_PLANE_BITS"] = str(a.plane_bits)      # the one-call entry point reads the lower bound from here
+
         def step(seqs=ds):
-            e = [ev() for _ in range(4)]
-            e[0].record()
-            pl = signatures_and_planes(e[1], seqs)
-            e[2].record()
-            device.mh_compare(pl, n, n_hash, 0, n, True, _capi.DA_OUT_F64, out=out)
-            e[3].record()
-            return e
-        phase_names = ["k1_signatures", "k1b_codes_to_planes", "k2_compare"]
+            """ONE C call (da_dev_similarity_mh): plan (duplicate collapse) + K1 + K1b + K2 [+ column gather + expansion];
+            it synchronises the stream, so the route's HIP-event phase times are final when it returns"""
+            device.similarity_mh(seqs, k, n_hash, d_seeds, out=out)
+            r = device.mh_last_route()
+            state["bits"] = r["plane_bits"]
+            return r
+        phase_names = ["plan_ms", "codes_ms", "k2_ms", "gather_ms", "expand_ms", "border_ms"]
     else:
         plan = sharding.Plan(n, rank, world, sharding.MH_TILE)
         work = sharding.PackedWorkspace(plan, n_hash, "cuda")   # counts travel in bits(n_hash) = 9 bits, not 16
@@ -255,25 +260,45 @@ def main():
         return max_over_ranks(time.perf_counter() - t0), evs
 
     dt, evs = timed_steps(step, a.steps, a.warmup)
-    phases = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i, nm in enumerate(phase_names)}
+    def phase_means(evs):
+        if world == 1:
+            return {nm: float(np.mean([e[nm] for e in evs])) for nm in phase_names}
+        return {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i, nm in enumerate(phase_names)}
+    phases = phase_means(evs)
+    route = evs[-1] if world == 1 else None
     ms_per_step = dt / a.steps * 1e3
     value = pairs_mh / (dt / a.steps)
 
-    def k2_roofline(k2_ms, plane_bits, wl_n=n):
+    def expand_roofline(rows_ms, wl_n=n):
+        """roofline object of k_expand_rows (the dominant kernel when the duplicate-collapsing route runs): per interior
+        off-diagonal 128 x 128 tile it reads 128 x 128 uint16 counts once and writes the tile twice as float64 (direct + mirrored)"""
+        Tf = wl_n // 128
+        tiles = Tf * (Tf - 1) // 2
+        bytes_x = tiles * 128 * 128 * (2 + 16)
+        t = rows_ms * 1e-3
+        traffic = pmc_traffic("k_expand_rows<false>", wl_n)
+        return {"kernel": "k_expand_rows<false>", "bound": "hbm", "achieved": bytes_x / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_x / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None, "avg_launch_ms": rows_ms,
+                "algorithmic_bytes_per_launch": bytes_x,
+                "note": "index expansion of the U x U count table to the dense f64 N x N: 2 B read + 16 B written per unordered pair"}
+
+    def k2_roofline(k2_ms, plane_bits, wl_n=n, out_elem=8):
         """roofline object of the compare kernel: algorithmic bytes (with the plane words actually read) /
         HIP-event duration, against the 8 TB/s HBM peak; + the VALU bound that actually binds"""
         k2 = k2_ms * 1e-3
         planes_row_bytes = 2 * 16 * plane_bits * 4        # two copies x 16 groups x planes x 4 B
         T = (wl_n + 127) // 128
         if world == 1:
-            bytes_k2 = wl_n * planes_row_bytes + wl_n * wl_n * 8   # read the bit planes once + write the f64 N x N
+            bytes_k2 = wl_n * planes_row_bytes + wl_n * wl_n * out_elem   # read the bit planes once + write the N x N (f64, or uint16 counts)
             tiles = T * (T + 1) // 2
         else:
             tiles = sum(T - t for t in range(rank, T, world))
             bytes_k2 = wl_n * planes_row_bytes + tiles * 128 * 128 * 2   # this rank's uint16 tiles
         lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
         # 12 / 16 code planes, symmetric mode: the hand-scheduled kernels do all but the diagonal / border tiles
-        k2_name = ("k_mh_compare_a%d<true>" % plane_bits) if (world == 1 and plane_bits in (12, 16)) else "k_mh_compare<true, true, %d>" % plane_bits
+        f64s = "true" if out_elem == 8 else "false"
+        k2_name = ("k_mh_compare_a%d<%s>" % (plane_bits, f64s)) if (world == 1 and plane_bits in (12, 16)) else "k_mh_compare<%s, true, %d>" % (f64s, plane_bits)
         traffic = pmc_traffic(k2_name, wl_n) if world == 1 else None
         return {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,
@@ -284,7 +309,13 @@ def main():
                          "lane_ops_per_launch": lane_ops, "achieved_lane_ops_per_s": lane_ops / k2,
                          "peak_lane_ops_per_s": BITOP3_PEAK, "frac": lane_ops / k2 / BITOP3_PEAK}}
 
-    k2_key = "k2_compare" if world == 1 else "k2_compare_shard"
+    k2_key = "k2_ms" if world == 1 else "k2_compare_shard"
+    if world == 1 and route["dedup"]:
+        # the timed step ran on the table of unique strings: its dominant kernel is the expansion; K2 on U rows rides along
+        main_roof = expand_roofline(phases["expand_ms"])
+        main_roof["k2_on_unique"] = k2_roofline(phases["k2_ms"], state["bits"], route["unique"], 2)
+    else:
+        main_roof = k2_roofline(phases[k2_key], state["bits"])
     line = {
         "metric": "sequence-pairs/sec (MinHash k=4 n_hash=500; NW BLOSUM62) at 1/2/4/8 MI355X",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -297,9 +328,25 @@ def main():
                    "n": n, "k": k, "n_hash": n_hash, "pairs": pairs_mh,
                    "sharding": "1 GPU: upper-triangle tiles + mirrored store" if world == 1
                    else "cyclic tile rows over %d ranks, one RCCL all-gather of the 9-bit packed counts, mirror+widen on every rank" % world},
-        "roofline": k2_roofline(phases[k2_key], state["bits"]),
+        "roofline": main_roof,
         "phases_ms": phases,
     }
+    if world == 1:
+        line["route"] = {"n": route["n"], "unique": route["unique"], "dedup": route["dedup"], "plane_bits": route["plane_bits"],
+                         "note": "dedup: byte-identical sequences collapsed (exact) -- K1 / K1b / K2 on the unique strings, then column gather + "
+                                 "index expansion to the dense N x N; direct: the three kernels on all N rows"}
+        if route["dedup"]:
+            os.environ["DYNAALIGN_MH_NO_DEDUP"] = "1"            # the same input with the route off: K2 on all N rows (what uniform peptides get)
+            try:
+                ddt, devs = timed_steps(step, max(2, min(a.steps, 3)), 1)
+            finally:
+                del os.environ["DYNAALIGN_MH_NO_DEDUP"]
+            dsteps = max(2, min(a.steps, 3))
+            dph = phase_means(devs)
+            line["direct"] = {"ms_per_step": ddt / dsteps * 1e3, "value": pairs_mh / (ddt / dsteps), "unit": "pairs/s", "steps": dsteps,
+                              "phases_ms": dph, "roofline": k2_roofline(dph["k2_ms"], state["bits"]),
+                              "note": "DYNAALIGN_MH_NO_DEDUP=1: every row goes through K1 / K1b / K2"}
+            state["bits"] = route["plane_bits"]
     if world > 1:
         line["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                         "all_gather_bytes_per_rank": int(work.block_bytes), "all_gather_ms": phases["all_gather"],
@@ -399,12 +446,12 @@ def main():
         uds = device.DeviceSequences(ures, uoff, "cuda")
         usteps = max(2, min(a.steps, 3))
         udt, uevs = timed_steps(lambda: step(uds), usteps, 1)
-        uph = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in uevs])) for i, nm in enumerate(phase_names)}
+        uph = phase_means(uevs)
         line["uniform"] = {"workload": "similarityMH k=4 n_hash=500 on %d uniform 20-mers (SURVEY 8(d) S100k), dense f64 NxN in HBM" % n,
                            "value": pairs_mh / (udt / usteps), "unit": "pairs/s", "ms_per_step": udt / usteps * 1e3, "steps": usteps,
-                           "plane_bits": state["bits"], "phases_ms": uph, "roofline": k2_roofline(uph["k2_compare"], state["bits"])}
+                           "plane_bits": state["bits"], "phases_ms": uph, "route": {"unique": uevs[-1]["unique"], "dedup": uevs[-1]["dedup"]},
+                           "roofline": k2_roofline(uph["k2_ms"], state["bits"])}
         del uds
-        signatures_and_planes()                       # back to the headline set (sig / planes are shared buffers)
 
     # ---- BASELINE configs[4]: clusterbreak(size_max=800, thresh_p=.8) end to end, GPU similarityMH backend on the
     # device edge path (signatures resident; per recursion level codes + compare + histogram + quantile + edges), host Louvain

@@ -45,6 +45,8 @@ SIGNATURES = {
     "da_dev_mh_planes": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _sz, _vp, _i64, _vp, _vp]),
     "da_dev_mh_compare": (_i32, [_vp, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "da_nw_last_route": (_i32, [_vp, _vp, _vp, _vp]),
+    "da_dev_similarity_mh": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "da_mh_last_route": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "da_similarity_mh_edges": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, C.c_double, _vp, _vp, _i64, _vp, _vp, _vp]),

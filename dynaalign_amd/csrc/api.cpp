@@ -47,32 +47,53 @@ namespace {
 
 // Large device buffers are kept for the next call instead of going back to the driver: hipMalloc / hipFree of the
 // 80 GB result buffer cost up to 3.2 s every other call on MI355X (profiles/r02_b_host_path_trace.txt) -- more than the
-// 1.5 s the PCIe copy of the result takes -- and clusterbreak calls sim_fn again and again.  At most two buffers per
-// device are parked; da_release_device_memory() returns them to the driver.
+// 1.5 s the PCIe copy of the result takes -- and clusterbreak calls sim_fn again and again.  Per device up to MAX_PARKED
+// buffers totalling at most 45 % of the device's memory are parked (one call of the duplicate-collapsing routes uses four:
+// plan, table, gathered table, plane workspace); a request takes the smallest parked buffer that fits it and is at most
+// twice its size (a 300 MB request must not walk away with the 9 GB buffer the next allocation of the same call wants);
+// when room is needed the smallest parked buffers go first (cheapest to allocate again).  da_release_device_memory()
+// returns everything to the driver, and so does an allocation of ours that would otherwise fail.
 struct BigCache {
   static constexpr size_t MIN_BYTES = (size_t)256 << 20;
+  static constexpr int MAX_PARKED = 8;
   struct Ent { int dev; void *p; size_t bytes; };
   std::mutex m;
   std::vector<Ent> parked;
+  std::vector<size_t> budget;                                   // per device: 45 % of its memory (0 = not asked yet)
+  size_t budget_of(int dev) {
+    if ((size_t)dev >= budget.size()) budget.resize((size_t)dev + 1, 0);
+    if (!budget[(size_t)dev]) {
+      size_t free_b = 0, total_b = 0;
+      budget[(size_t)dev] = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b / 100 * 45 : (size_t)64 << 30;
+    }
+    return budget[(size_t)dev];
+  }
   void *take(int dev, size_t bytes, size_t *cap) {
     std::lock_guard<std::mutex> g(m);
     size_t best = parked.size();
     for (size_t i = 0; i < parked.size(); ++i)
-      if (parked[i].dev == dev && parked[i].bytes >= bytes && (best == parked.size() || parked[i].bytes < parked[best].bytes)) best = i;
+      if (parked[i].dev == dev && parked[i].bytes >= bytes && parked[i].bytes / 2 <= bytes &&
+          (best == parked.size() || parked[i].bytes < parked[best].bytes)) best = i;
     if (best == parked.size()) return nullptr;
     void *p = parked[best].p;
     *cap = parked[best].bytes;
     parked.erase(parked.begin() + (long)best);
     return p;
   }
-  void park(int dev, void *p, size_t bytes) {
+  void park(int dev, void *p, size_t bytes) {                   // (the caller has made `dev` current)
     std::lock_guard<std::mutex> g(m);
-    int mine = 0;
-    size_t smallest = parked.size();
-    for (size_t i = 0; i < parked.size(); ++i)
-      if (parked[i].dev == dev) { ++mine; if (smallest == parked.size() || parked[i].bytes < parked[smallest].bytes) smallest = i; }
-    if (mine >= 2) {                                   // keep the two largest
-      if (parked[smallest].bytes >= bytes) { (void)hipFree(p); return; }
+    const size_t cap_bytes = budget_of(dev);
+    if (bytes > cap_bytes) { (void)hipFree(p); return; }
+    for (;;) {
+      int mine = 0;
+      size_t sum = 0, smallest = parked.size();
+      for (size_t i = 0; i < parked.size(); ++i)
+        if (parked[i].dev == dev) {
+          ++mine; sum += parked[i].bytes;
+          if (smallest == parked.size() || parked[i].bytes < parked[smallest].bytes) smallest = i;
+        }
+      if (mine < MAX_PARKED && sum + bytes <= cap_bytes) break;
+      if (parked[smallest].bytes >= bytes) { (void)hipFree(p); return; }   // everything parked is bigger: the newcomer goes
       (void)hipFree(parked[smallest].p);
       parked.erase(parked.begin() + (long)smallest);
     }
@@ -497,6 +518,111 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
                            static_cast<hipStream_t>(stream), plane_bits);
 }
 
+// similarityMH, packed residues in HBM -> dense float64 n x n in HBM, as ONE call (K1 + K1b + K2 and the route below).
+// Byte-identical sequences have identical signatures, hence identical rows and columns of the result: when at least 15 % of the
+// sequences are duplicates the pipeline runs on the table of U unique strings (the plan of the NW route: nw_kernels.hip
+// "duplicate sequences"; MinHash similarity IS symmetric, so the plain symmetric compare on U rows does) -- K2's work shrinks by
+// (U/n)^2 -- and the n x n matrix is an index expansion of the U x U count table (launch_expand_unique's two streaming passes,
+// 5.7 TB/s of stores).  Exact.  Otherwise (uniform peptides: nothing to collapse), or when the expansion's fast passes do not cover the shape
+// (U > 65536, n_hash > 2047, n < 2048), the direct kernels run.  Synchronises `stream` (K1b reads the dictionary sizes back).
+// DYNAALIGN_MH_NO_DEDUP=1 switches the route off.
+struct MhRoute { int64_t n = 0, unique = 0; int taken = 0, plane_bits = 0; float ms[6] = {0, 0, 0, 0, 0, 0}; };   // plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles
+static MhRoute &mh_route() { static thread_local MhRoute r; return r; }
+
+static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t n, int64_t total, int k, int n_hash,
+                             const uint32_t *d_seeds, double *d_out, int64_t ld, hipStream_t stream) {
+  int rc;
+  MhRoute &route = mh_route();
+  route = MhRoute();
+  route.n = route.unique = n;
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 7; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } guard{ev};
+  for (auto &e : ev) DA_HIP_TRY(hipEventCreate(&e));
+  DA_HIP_TRY(hipEventRecord(ev[0], stream));
+  const int64_t lds = sig_ld_for(n_hash);
+  int64_t min_n = 2048;
+  if (const char *e = getenv("DYNAALIGN_MH_DEDUP_MIN_N")) min_n = atoll(e);   // tests lower it to reach the route with small inputs
+  const bool eligible = n >= min_n && n <= 0x7ffffff0LL && total > 0 && n_hash <= 2047 && !getenv("DYNAALIGN_MH_NO_DEDUP");
+  DevBuf plan_work;
+  NwDedupPlan p{};
+  int64_t U = n;
+  bool take = false;
+  if (eligible) {
+    if ((rc = plan_work.alloc(nw_dedup_workspace_bytes(n, total))) != DA_OK) return rc;
+    p = nw_dedup_layout(plan_work.p, n, total);
+    if ((rc = launch_nw_dedup_count(d_res, d_off, n, p, stream)) != DA_OK) return rc;
+    int32_t M = 0, S = 0;
+    DA_HIP_TRY(hipMemcpyAsync(&M, p.pm + n, 4, hipMemcpyDeviceToHost, stream));
+    DA_HIP_TRY(hipMemcpyAsync(&S, p.ps + n, 4, hipMemcpyDeviceToHost, stream));
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+    U = (int64_t)M + S;
+    route.unique = U;
+    take = U > 0 && U * 100 <= n * 85 && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
+    if (take && (rc = launch_nw_dedup_build(d_res, d_off, n, U, p, stream)) != DA_OK) return rc;
+  }
+  DA_HIP_TRY(hipEventRecord(ev[1], stream));
+  const int64_t m = take ? U : n;                                   // rows the kernels see
+  const uint8_t *res_m = take ? p.ucodes : d_res;
+  const int64_t *off_m = take ? p.uoff : d_off;
+  DevBuf sig, planes, pwork;
+  const size_t wb = mh_planes_workspace_bytes(m, n_hash);
+  if ((rc = sig.alloc((size_t)m * lds * sizeof(uint32_t))) != DA_OK) return rc;
+  if ((rc = planes.alloc((size_t)mh_planes_words(m, n_hash) * sizeof(uint32_t))) != DA_OK) return rc;
+  if ((rc = pwork.alloc(wb)) != DA_OK) return rc;
+  if ((rc = launch_minhash_signatures(res_m, off_m, m, k, n_hash, d_seeds, sig.as<uint32_t>(), lds, stream)) != DA_OK) return rc;
+  int bits = 32;
+  if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream)) != DA_OK) return rc;
+  route.plane_bits = bits;
+  DA_HIP_TRY(hipEventRecord(ev[2], stream));
+  if (!take) {
+    if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, DA_OUT_F64, d_out, ld, stream, bits)) != DA_OK) return rc;
+    DA_HIP_TRY(hipEventRecord(ev[3], stream));
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+    (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
+    (void)hipEventElapsedTime(&route.ms[1], ev[1], ev[2]);
+    (void)hipEventElapsedTime(&route.ms[2], ev[2], ev[3]);
+    return DA_OK;
+  }
+  const int64_t ld_d = (U + 7) / 8 * 8;
+  DevBuf dtab, ftab;
+  if ((rc = dtab.alloc((size_t)U * (size_t)ld_d * 2)) != DA_OK) return rc;
+  if ((rc = ftab.alloc(expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0))) != DA_OK) return rc;
+  if ((rc = launch_mh_compare(planes.as<uint32_t>(), U, n_hash, 0, U, true, DA_OUT_COMPACT, dtab.p, ld_d, stream, bits)) != DA_OK) return rc;
+  DA_HIP_TRY(hipEventRecord(ev[3], stream));
+  if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, DA_OUT_F64, false, n_hash, d_out, ld, stream, 0, ftab.as<uint16_t>(),
+                                 p.ufirst, U, ev[4], ev[5])) != DA_OK) return rc;
+  DA_HIP_TRY(hipEventRecord(ev[6], stream));
+  DA_HIP_TRY(hipStreamSynchronize(stream));                         // the buffers go back to the parked-buffer cache here
+  route.taken = 1;
+  (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
+  (void)hipEventElapsedTime(&route.ms[1], ev[1], ev[2]);
+  (void)hipEventElapsedTime(&route.ms[2], ev[2], ev[3]);
+  (void)hipEventElapsedTime(&route.ms[3], ev[3], ev[4]);
+  (void)hipEventElapsedTime(&route.ms[4], ev[4], ev[5]);
+  (void)hipEventElapsedTime(&route.ms[5], ev[5], ev[6]);
+  return DA_OK;
+}
+
+int da_dev_similarity_mh(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n, int64_t total_residues, int k, int n_hash,
+                         const uint32_t *d_seeds, double *d_out, int64_t ld, void *stream) {
+  int rc = validate_mh(n, k, n_hash);
+  if (rc != DA_OK) return rc;
+  if (!d_residues || !d_offsets || !d_seeds || !d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if (ld < n) return fail(DA_ERR_BAD_ARG, "ld (%lld) < n (%lld)", (long long)ld, (long long)n);
+  if (n_hash > 65535) return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d); da_similarity_mh handles more", n_hash);
+  return mh_full_symmetric(d_residues, d_offsets, n, total_residues, k, n_hash, d_seeds, d_out, ld, static_cast<hipStream_t>(stream));
+}
+
+int da_mh_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, int *plane_bits_out, double *ms6_out) {
+  const MhRoute &r = mh_route();
+  if (n_out) *n_out = r.n;
+  if (unique_out) *unique_out = r.unique;
+  if (dedup_taken_out) *dedup_taken_out = r.taken;
+  if (plane_bits_out) *plane_bits_out = r.plane_bits;
+  if (ms6_out) for (int i = 0; i < 6; ++i) ms6_out[i] = r.ms[i];
+  return DA_OK;
+}
+
 int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues, uint8_t *d_codes,
                      int32_t *d_bad, void *stream) {
   if (total_residues > 0 && (!d_residues || !d_codes || !d_bad)) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
@@ -550,7 +676,11 @@ static int nw_full_symmetric(const uint8_t *d_codes, const int64_t *d_offsets, i
       if ((rc = launch_nw(p.ucodes, p.uoff, U, max_len, mid, gap_open, gap_ext, 0, U, false, DA_OUT_COMPACT, dtab.p, ld_d, nullptr, 0,
                           stream, 0, 0, p.ufirst, p.minfirst, p.maxlast)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(ev[2], stream));
-      if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, kind, true, 0, d_out, ld, stream)) != DA_OK) return rc;
+      DevBuf ftab;                                        // column-gathered twin of the table for the two-pass expansion
+      const size_t fbytes = expand_rows_workspace_bytes(n, U, kind, true, 0, (int)max_len);
+      if (fbytes && (rc = ftab.alloc(fbytes)) != DA_OK) return rc;
+      if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, kind, true, 0, d_out, ld, stream, (int)max_len,
+                                     fbytes ? ftab.as<uint16_t>() : nullptr, p.ufirst, U)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(ev[3], stream));
       DA_HIP_TRY(hipStreamSynchronize(stream));          // work / dtab go back to the parked-buffer cache here
       route.taken = 1;

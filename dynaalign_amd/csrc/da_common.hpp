@@ -152,7 +152,10 @@ int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t 
 int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t U, const NwDedupPlan &p, hipStream_t stream);
 // minhash_kernels.hip: out[i][j] = value(D[uidx[min(i,j)]][uidx[max(i,j)]]) for the dense symmetric n x n result
 int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
-                         void *d_out, int64_t ld, hipStream_t stream);
+                         void *d_out, int64_t ld, hipStream_t stream, int nw_max_len = 0, uint16_t *d_F = nullptr,
+                         const int32_t *d_ufirst = nullptr, int64_t U = 0, hipEvent_t after_gather = nullptr, hipEvent_t after_rows = nullptr);
+// bytes of the column-gathered table (d_F) that switches launch_expand_unique to its two streaming passes; 0 = shape not covered
+size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, int n_hash, int nw_max_len);
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
                            hipStream_t stream, int rank = 0, int world = 0);
 int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,

@@ -9,6 +9,7 @@
 // work; no MFMA (an equality count is not a contraction).
 #include "da_common.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 
@@ -1438,15 +1439,26 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
 // 64 x 64 output tiles on or above the diagonal in the banded XCD order of k_finalize_sharded, gathered through LDS so that
 // the mirrored half is written as row pieces too.  Single-copy strings are numbered in input order, so most of a row's
 // gather hits consecutive table columns; the multi-copy ones sit in the first few KiB of every table row.
+__device__ __forceinline__ bool expand_fast_takes(int ti128, int tj128, int n, int64_t ld, const void *out);
 template <bool F64, bool IS_NW, int FT>
 __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                        int n, int n_hash, void *__restrict__ out_v, int64_t ld, int TB,
-                                                       int64_t ntiles, int64_t per_xcd) {
+                                                       int64_t ntiles, int64_t per_xcd, int skip_fast) {
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ int32_t ur[FT], uc[FT];
-  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (L >= ntiles) return;
-  const TileId tt = decode_tile(L, TB, TB, true);
+  TileId tt;
+  if (skip_fast) {
+    // only what k_expand_rows leaves (FT = 64): block b -> quarter (b & 3) of 128-tile b >> 2, the T128 diagonal tiles first, then
+    // the last tile column when n is not a multiple of 128
+    const int T128 = (n + 127) >> 7, t = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    const int ti128 = t < T128 ? t : t - T128, tj128 = t < T128 ? t : T128 - 1;
+    tt.ti = 2 * ti128 + (sub >> 1); tt.tj = 2 * tj128 + (sub & 1);
+    tt.valid = tt.ti <= tt.tj && tt.ti < TB && tt.tj < TB;
+  } else {
+    const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (L >= ntiles) return;
+    tt = decode_tile(L, TB, TB, true);
+  }
   if (!tt.valid) return;
   const int i0 = tt.ti * FT, j0 = tt.tj * FT;
   constexpr int RS = 256 / FT;
@@ -1487,8 +1499,129 @@ __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restric
   }
 }
 
+// The same expansion for the interior off-diagonal 128 x 128 tiles (99 % of the result at N = 100k), as two streaming passes.
+// The one-kernel form above gathers every output entry by its own 2-byte read -- 64 load instructions per lane and tile, each
+// touching up to 64 lines: 24 ms for the 80 GB result (3.4 TB/s).  Here
+//   k_gather_columns:  F[r][j] = D[r][uidx[j]]  for every unique row r and every column j right of r's first tile -- the row of D
+//                      sits in LDS, so the random access costs LDS cycles, and both global sides are coalesced;
+//   k_expand_rows:     out[i][j] = out[j][i] = value(F[uidx[i]][j]) -- a tile is 128 row pieces of 256 consecutive bytes (16-byte
+//                      loads -> LDS), every lane then owns an 8 x 8 block exactly like k_mh_compare's epilogue: no transpose, the
+//                      mirrored 16-byte store of rows r, r+1 at one column uses values the lane already holds.
+// The tiles they take (expand_fast_takes) are skipped by k_expand_unique, which keeps diagonal and border tiles.
+__device__ __forceinline__ bool expand_fast_takes(int ti128, int tj128, int n, int64_t ld, const void *out) {
+  return ti128 != tj128 && (ti128 + 1) * 128 <= n && (tj128 + 1) * 128 <= n && (ld & 1) == 0 &&
+         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+}
+constexpr int GC_THREADS = 1024;
+// one resident workgroup per CU walks the unique rows r = blockIdx.x, + gridDim.x, ...: the NEXT row is already on its way into
+// registers while the current one is gathered out of LDS (U <= 65536 -> at most 8 16-byte units per thread)
+__global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
+                                                               const int32_t *__restrict__ ufirst, int n, int U, uint16_t *__restrict__ F,
+                                                               int64_t ld_f) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t gc_row[];   // ld_d entries
+  const int units = (int)(ld_d >> 3);
+  uint4 pre[8];
+#define GC_FETCH(row)                                                                                   \
+  {                                                                                                     \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(D + (int64_t)(row) * ld_d);                     \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                     \
+      const int u = (int)threadIdx.x + q * GC_THREADS;                                                  \
+      pre[q] = u < units ? src_[u] : make_uint4(0, 0, 0, 0);                                            \
+    }                                                                                                   \
+  }
+  int r = blockIdx.x;
+  if (r < U) GC_FETCH(r)
+  const int2 *u2 = reinterpret_cast<const int2 *>(uidx);
+  const int j2_end = n >> 1;                                         // (an odd last column is a border column)
+  for (; r < U; r += gridDim.x) {
+    __syncthreads();                                                 // the previous row's gather has left the LDS row
+    uint4 *dst = reinterpret_cast<uint4 *>(gc_row);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int u = (int)threadIdx.x + q * GC_THREADS;
+      if (u < units) dst[u] = pre[q];
+    }
+    __syncthreads();
+    if (r + (int)gridDim.x < U) GC_FETCH(r + (int)gridDim.x)
+    const int j_begin = ((ufirst[r] >> 7) + 1) << 7;                 // first column of the tile right of r's first occurrence:
+    uint32_t *frow = reinterpret_cast<uint32_t *>(F + (int64_t)r * ld_f);   // interior tiles never read this row left of it
+    for (int j2 = (j_begin >> 1) + threadIdx.x; j2 < j2_end; j2 += GC_THREADS) {
+      const int2 c = u2[j2];
+      __builtin_nontemporal_store((uint32_t)gc_row[c.x] | ((uint32_t)gc_row[c.y] << 16), frow + j2);
+    }
+  }
+#undef GC_FETCH
+}
+
+constexpr int ER_STRIDE = 272;   // bytes per staged tile row: 256 + 16 -- the lanes' 4-byte reads (row 2 ty, word tx) fall into 64 distinct banks
+template <bool IS_NW>
+__global__ __launch_bounds__(256, 4) void k_expand_rows(const uint16_t *__restrict__ F, int64_t ld_f, const int32_t *__restrict__ uidx,
+                                                        int n, int n_hash, int tab_stride, int tab_entries, double *__restrict__ out,
+                                                        int64_t ld, int T128, int64_t ntiles, int64_t per_xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char er_lds[];   // 128 x ER_STRIDE tile, then the value table
+  double *tab = reinterpret_cast<double *>(er_lds + 128 * ER_STRIDE);
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= ntiles) return;
+  const TileId tt = decode_tile(L, T128, T128, true);
+  if (!tt.valid || !expand_fast_takes(tt.ti, tt.tj, n, ld, out)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tx = ((wave & 1) << 3) + (lane & 7), ty = ((wave >> 1) << 3) + (lane >> 3);
+  const int64_t I0 = (int64_t)tt.ti * 128, J0 = (int64_t)tt.tj * 128;
+  // stage: thread t moves 16-byte unit (t & 15) of rows (t >> 4) + 16 q
+  uint4 st[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = (tid >> 4) + 16 * q;
+    st[q] = *(reinterpret_cast<const uint4 *>(F + (int64_t)uidx[I0 + row] * ld_f + J0) + (tid & 15));
+  }
+  if (IS_NW) {
+    for (int e = tid; e < tab_entries; e += 256) {
+      const int mt = e / tab_stride, ln = e - mt * tab_stride;
+      tab[e] = ln == 0 ? __longlong_as_double(0xFFF8000000000000ULL) : (double)mt / (double)ln;   // src/pairwiseSeqAlign.cpp:311
+    }
+  } else {
+    for (int e = tid; e < tab_entries; e += 256) tab[e] = (double)e / (double)n_hash;              // src/minHash.cpp:174
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    *reinterpret_cast<uint4 *>(er_lds + ((tid >> 4) + 16 * q) * ER_STRIDE + (tid & 15) * 16) = st[q];
+  __syncthreads();
+  auto widen = [&](uint32_t x) -> double {
+    if (IS_NW) return tab[(x >> 8) * (uint32_t)tab_stride + (x & 255u)];
+    return tab[x];
+  };
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    double v0[8], v1[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w0 = *reinterpret_cast<const uint32_t *>(er_lds + (32 * g + 2 * ty) * ER_STRIDE + (32 * q + 2 * tx) * 2);
+      const uint32_t w1 = *reinterpret_cast<const uint32_t *>(er_lds + (32 * g + 2 * ty + 1) * ER_STRIDE + (32 * q + 2 * tx) * 2);
+      v0[2 * q] = widen(w0 & 0xffffu); v0[2 * q + 1] = widen(w0 >> 16);
+      v1[2 * q] = widen(w1 & 0xffffu); v1[2 * q + 1] = widen(w1 >> 16);
+    }
+    double *orow = out + (I0 + 32 * g + 2 * ty) * ld + (J0 + 2 * tx);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      nt_store2(orow + 32 * q, v0[2 * q], v0[2 * q + 1]);
+      nt_store2(orow + ld + 32 * q, v1[2 * q], v1[2 * q + 1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      nt_store2(out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 32 * g + 2 * ty), v0[c], v1[c]);
+  }
+}
+
+// device bytes of the column-gathered table the two-pass expansion wants (0: the shape is not covered, pass NULL)
+size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, int n_hash, int nw_max_len) {
+  if (kind != DA_OUT_F64 || n < 256 || U > 65536 || U < 1 || getenv("DYNAALIGN_EXPAND_NO_FAST")) return 0;
+  if (is_nw ? (nw_max_len < 1 || (int64_t)(nw_max_len + 1) * (2 * nw_max_len + 1) > 2048) : (n_hash < 1 || n_hash + 1 > 2048)) return 0;
+  return (size_t)U * (size_t)(ceil_div(n, 8) * 8) * 2;
+}
+
 int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
-                         void *d_out, int64_t ld, hipStream_t stream) {
+                         void *d_out, int64_t ld, hipStream_t stream, int nw_max_len, uint16_t *d_F, const int32_t *d_ufirst, int64_t U,
+                         hipEvent_t after_gather, hipEvent_t after_rows) {
   if (n <= 0) return DA_OK;
   if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "expand: matrix too large");
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "expand: bad output kind");
@@ -1497,8 +1630,50 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   const int64_t per_xcd = ceil_div(tiles, 8);
-  const dim3 grid((unsigned)(per_xcd * 8));
-#define DA_EXP(F, W, T) hipLaunchKernelGGL((k_expand_unique<F, W, T>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd)
+  dim3 grid((unsigned)(per_xcd * 8));
+  // float64 with a column-gathered table from the caller: interior off-diagonal 128 x 128 tiles by the two streaming passes,
+  // the rest (diagonal, borders) by the 64 x 64 kernel below
+  const bool fast = d_F != nullptr && expand_rows_workspace_bytes(n, U, kind, is_nw, n_hash, nw_max_len) != 0 && (ld & 1) == 0 &&
+                    (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && ft == 64;
+  if (fast) {
+    const int64_t ld_f = ceil_div(n, 8) * 8;
+    const size_t row_bytes = (size_t)ld_d * 2;
+    static bool attr_done = false;   // (idempotent; a race sets the same value twice)
+    if (!attr_done) {
+      DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_columns), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
+      attr_done = true;
+    }
+    static std::atomic<int> gc_cus;
+    if (!gc_cus.load()) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      DA_HIP_TRY(hipGetDevice(&dev));
+      DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+      gc_cus.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    }
+    const int gc_wg = row_bytes <= 40 * 1024 ? 2 : 1;                  // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
+    const int64_t gc_grid = std::min<int64_t>(U, (int64_t)gc_cus.load() * gc_wg);
+    hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)gc_grid), dim3(GC_THREADS), row_bytes, stream, d_D, ld_d, d_uidx, d_ufirst, (int)n,
+                       (int)U, d_F, ld_f);
+    if (after_gather) DA_HIP_TRY(hipEventRecord(after_gather, stream));
+    const int T128 = (int)ceil_div(n, 128);
+    const int64_t t128 = (int64_t)T128 * (T128 + 1) / 2, px = ceil_div(t128, 8);
+    const int stride = is_nw ? 2 * nw_max_len + 1 : 1;
+    const int entries = is_nw ? (nw_max_len + 1) * stride : n_hash + 1;
+    const size_t lds = 128 * ER_STRIDE + (size_t)entries * 8;
+    if (is_nw) hipLaunchKernelGGL(k_expand_rows<true>, dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_F, ld_f, d_uidx, (int)n, n_hash,
+                                  stride, entries, static_cast<double *>(d_out), ld, T128, t128, px);
+    else hipLaunchKernelGGL(k_expand_rows<false>, dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_F, ld_f, d_uidx, (int)n, n_hash,
+                            stride, entries, static_cast<double *>(d_out), ld, T128, t128, px);
+  }
+  else if (after_gather) DA_HIP_TRY(hipEventRecord(after_gather, stream));
+  if (after_rows) DA_HIP_TRY(hipEventRecord(after_rows, stream));
+  const int skip_fast = fast ? 1 : 0;
+  if (fast) {   // the 64 x 64 kernel then only visits the diagonal 128-tiles and the border column
+    const int T128 = (int)ceil_div(n, 128);
+    grid.x = (unsigned)(4 * (T128 + ((n & 127) ? T128 - 1 : 0)));
+  }
+#define DA_EXP(F, W, T) hipLaunchKernelGGL((k_expand_unique<F, W, T>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd, skip_fast)
   if (ft == 128) {
     if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 128); else DA_EXP(true, false, 128); }
     else { if (is_nw) DA_EXP(false, true, 128); else DA_EXP(false, false, 128); }

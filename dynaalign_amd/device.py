@@ -206,6 +206,31 @@ def extract_edges(compact, n, keep, capacity, include_diagonal=True):
     return ei, ej, ev, cnt
 
 
+def similarity_mh(ds, k, n_hash, seeds, out=None):
+    """similarityMH (src/minHash.cpp:119-188) on a device-resident set, one C call: K1 + K1b + K2, with byte-identical
+    sequences collapsed first when that pays (da_dev_similarity_mh).  Returns the (n, n) float64 tensor."""
+    lib = _capi.load()
+    if not torch.is_tensor(seeds):
+        seeds = torch.from_numpy(np.ascontiguousarray(seeds, np.uint32).view(np.int32).copy()).to(ds.residues.device)
+    _require_cuda(ds.residues, "residues")
+    n = ds.n
+    if out is None:
+        out = torch.empty((max(n, 1), max(n, 1)), dtype=torch.float64, device=ds.residues.device)
+    _capi.check(lib.da_dev_similarity_mh(ds.residues.data_ptr(), ds.offsets.data_ptr(), n, ds.total, int(k), int(n_hash),
+                                         seeds.data_ptr(), out.data_ptr(), out.stride(0), _stream()))
+    return out
+
+
+def mh_last_route():
+    """what this thread's last similarity_mh call did: dict(n, unique, dedup, plane_bits, plan_ms, codes_ms, k2_ms, gather_ms, expand_ms, border_ms)"""
+    n, u, t, b = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+    ms = (ctypes.c_double * 6)()
+    _capi.check(_capi.load().da_mh_last_route(ctypes.addressof(n), ctypes.addressof(u), ctypes.addressof(t), ctypes.addressof(b),
+                                              ctypes.addressof(ms)))
+    return {"n": n.value, "unique": u.value, "dedup": bool(t.value), "plane_bits": b.value, "plan_ms": ms[0], "codes_ms": ms[1],
+            "k2_ms": ms[2], "gather_ms": ms[3], "expand_ms": ms[4], "border_ms": ms[5]}
+
+
 def nw_last_route():
     """what this thread's last whole-matrix NW call did: dict(n, unique, dedup, plan_ms, dp_ms, expand_ms)"""
     n, u, t = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)

@@ -204,6 +204,21 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
                       int64_t row_begin, int64_t row_end, int symmetric,
                       int kind, void *d_out, int64_t ld, void *stream);
 
+/* K1 + K1b + K2 as ONE call: similarityMH (src/minHash.cpp:119-188) from packed residues in HBM to the dense float64
+ * n x n matrix in HBM (d_out, leading dimension ld >= n doubles; 16-byte aligned and even ld for the wide-store kernels).
+ * Byte-identical sequences have identical signatures, so -- like da_dev_nw -- the call first collapses them: signatures,
+ * dictionary codes and the compare run on the U unique strings (K2's work shrinks by (U/n)^2) and the n x n matrix is an
+ * index expansion of the U x U count table in two streaming passes.  Exact; taken when >= 15 % of the sequences are
+ * duplicates, n >= 2048, U <= 65536, n_hash <= 2047; otherwise the three kernels run on all n rows (what uniform peptides
+ * get).  Allocates its intermediates itself (parked between calls, da_release_device_memory frees them) and synchronises
+ * the stream.  DYNAALIGN_MH_NO_DEDUP=1 disables the route.  da_mh_last_route reports what the calling thread's last such
+ * call did: n, unique strings, whether the route was taken, the plane count K1b chose, and the times in ms of
+ * {plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles} (direct route: {plan, K1 + K1b, K2, 0, 0, 0}).
+ * Any pointer may be NULL. */
+int da_dev_similarity_mh(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n, int64_t total_residues,
+                         int k, int n_hash, const uint32_t *d_seeds, double *d_out, int64_t ld, void *stream);
+int da_mh_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, int *plane_bits_out, double *ms6_out);
+
 /* K0: validate + encode residues to BLOSUM row indices 0..23
  * (src/pairwiseSeqAlign.cpp:15-21).  d_codes[total]; *d_bad (int32, caller
  * zeroes it) becomes INT32_MAX - (smallest offending byte position) if any

@@ -1,0 +1,120 @@
+"""GPU tests of the duplicate-collapsing route of similarityMH (api.cpp mh_full_symmetric = da_dev_similarity_mh): byte-identical
+sequences are collapsed, K1 / K1b / K2 run on the table of unique strings and the n x n matrix is an index expansion of the
+U x U count table (minhash_kernels.hip: k_gather_columns + k_expand_rows for interior tiles, k_expand_unique for diagonal and
+border tiles).  Must be bit-identical to the three kernels run on all n rows and to the oracle (reference src/minHash.cpp:119-188)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def da(built):
+    import dynaalign_amd
+    from dynaalign_amd import _capi
+    assert _capi.load().da_device_count() > 0
+    return dynaalign_amd
+
+
+@pytest.fixture()
+def small_n_route(monkeypatch):
+    monkeypatch.setenv("DYNAALIGN_MH_DEDUP_MIN_N", "1")
+
+
+def oracle(seqs, k, n_hash, seed=12345):
+    rc, m = O.similarity_mh(seqs, k, n_hash, O.seeds(seed, n_hash))
+    assert rc == 0
+    return m
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def run(seqs, k, n_hash, seed=12345, direct=False):
+    import torch
+    from dynaalign_amd import device, synth
+    import dynaalign_amd as da_
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(np.asarray(res, np.uint8), np.asarray(off, np.int64))
+    seeds = da_.hash_family_seeds(seed, n_hash)
+    if direct:
+        os.environ["DYNAALIGN_MH_NO_DEDUP"] = "1"
+    try:
+        out = device.similarity_mh(ds, k, n_hash, seeds)
+        torch.cuda.synchronize()
+        route = device.mh_last_route()
+    finally:
+        os.environ.pop("DYNAALIGN_MH_NO_DEDUP", None)
+    return out.cpu().numpy(), route
+
+
+def duplicated_set(rng, n_pool, n_draw, n_single, lo=0, hi=41):
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    mk = lambda: "".join(map(chr, alpha[rng.randint(0, 20, rng.randint(lo, hi))]))
+    pool = [mk() for _ in range(n_pool)]
+    seqs = [pool[q] for q in rng.randint(0, n_pool, n_draw)] + [mk() for _ in range(n_single)]
+    rng.shuffle(seqs)
+    return seqs
+
+
+@pytest.mark.parametrize("seed,n_hash,k", [(1, 50, 4), (2, 500, 4), (3, 33, 2)])
+def test_route_matches_direct_and_oracle(da, small_n_route, seed, n_hash, k):
+    """few distinct strings drawn many times in random order + singletons, ragged lengths (some shorter than k, some empty)"""
+    rng = np.random.RandomState(seed)
+    seqs = duplicated_set(rng, 50, 600, 130)
+    got, route = run(seqs, k, n_hash)
+    assert route["dedup"] and route["unique"] == len(set(seqs)) and route["n"] == len(seqs)
+    direct, droute = run(seqs, k, n_hash, direct=True)
+    assert not droute["dedup"]
+    want = oracle(seqs, k, n_hash)
+    assert same(direct, want)
+    assert same(got, want)
+
+
+def test_interior_tiles_take_the_two_pass_expansion(da, small_n_route):
+    """n = 1000 (7 full 128-tiles + a border): interior off-diagonal tiles go through k_gather_columns + k_expand_rows, the rest
+    through k_expand_unique; an odd n puts the last column on the border path"""
+    rng = np.random.RandomState(7)
+    for n_draw, n_single in ((800, 200), (900, 101)):
+        seqs = duplicated_set(rng, 120, n_draw, n_single, 8, 25)
+        got, route = run(seqs, 4, 100)
+        assert route["dedup"]
+        direct, _ = run(seqs, 4, 100, direct=True)
+        assert same(got, direct)
+        want = oracle(seqs, 4, 100)
+        assert same(got, want)
+
+
+def test_route_not_taken_without_duplicates(da, small_n_route):
+    rng = np.random.RandomState(11)
+    seqs = duplicated_set(rng, 1, 0, 400, 15, 25)
+    got, route = run(seqs, 4, 64)
+    assert not route["dedup"] and route["unique"] >= 0.85 * len(seqs)
+    assert same(got, oracle(seqs, 4, 64))
+
+
+def test_h3n2_like_12000_properties(da):
+    """the headline generator at a size the default threshold (n >= 2048) reaches: both routes agree bit for bit; symmetric, unit diagonal"""
+    import torch
+    from dynaalign_amd import device, synth
+    import dynaalign_amd as da_
+    n = 12000
+    res, off = synth.h3n2_like(n, 20)
+    ds = device.DeviceSequences(res, off)
+    seeds = da_.hash_family_seeds(12345, 500)
+    out = device.similarity_mh(ds, 4, 500, seeds)
+    route = device.mh_last_route()
+    assert route["dedup"] and route["unique"] == len(set(synth.to_strings(res, off)))
+    os.environ["DYNAALIGN_MH_NO_DEDUP"] = "1"
+    try:
+        direct = device.similarity_mh(ds, 4, 500, seeds)
+    finally:
+        del os.environ["DYNAALIGN_MH_NO_DEDUP"]
+    assert torch.equal(out.view(torch.int64), direct.view(torch.int64))
+    assert torch.equal(out, out.T) and bool((out.diagonal() == 1.0).all())
