@@ -32,20 +32,22 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Folded layout of one rank's shard (row-sharded multi-GPU path).  Rank p owns tile rows
 // t = q*world + p (q = 0..Q-1) and only their part right of the diagonal is valid, so local
-// tile rows q and Q-1-q share one stored tile row of width W = n + world*tile (rounded up to
-// 8): the first left-aligned from its diagonal tile, the second right-aligned.  That halves
-// the bytes the all-gather has to move.
+// tile rows q and Q-1-q share one stored tile row of width W = ceil8(n) + world*tile: the first
+// left-aligned from its diagonal tile, the second starting at column shard_back(W, n) = W - ceil8(n)
+// (so both start on a multiple of 8 columns: 16-byte loads of row pieces stay aligned).  That
+// halves the bytes the all-gather has to move.
 struct ShardGeom {
   int64_t n, W, rows;  // rows = local rows per rank
   int world, tile, T, Q, Qh;
 };
+__host__ __device__ inline int64_t shard_back(int64_t W, int64_t n) { return W - ((n + 7) / 8) * 8; }   // local column of global column 0 in a back-aligned row
 inline ShardGeom shard_geom(int64_t n, int world, int tile) {
   ShardGeom g;
   g.n = n; g.world = world; g.tile = tile;
   g.T = (int)ceil_div(n, tile);
   g.Q = (int)ceil_div(g.T, world);
   g.Qh = (g.Q + 1) / 2;
-  g.W = ceil_div(n + (int64_t)world * tile, 8) * 8;
+  g.W = ceil_div(n, 8) * 8 + (int64_t)world * tile;
   g.rows = (int64_t)g.Qh * tile;
   return g;
 }
@@ -125,7 +127,7 @@ int launch_ids_to_planes(const void *d_work, int64_t n, int n_hash, int plane_bi
 int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, uint32_t *d_planes,
                          hipStream_t stream);
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
-                            double *d_out, int64_t ld, hipStream_t stream);
+                            double *d_out, int64_t ld, hipStream_t stream);   // interior tiles: k_finalize_rows (16-byte stores)
 int64_t shard_packed_bytes(const ShardGeom &g, int value_bits);
 int launch_pack_shard(const uint16_t *d_local, int64_t ld, const ShardGeom &geom, int value_bits, uint8_t *d_packed,
                       hipStream_t stream);

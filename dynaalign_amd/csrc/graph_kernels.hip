@@ -46,7 +46,7 @@ __device__ __forceinline__ bool locate_tile(const Layout &lay, int64_t L, int T,
   if (ti >= T || tj < ti) return false;
   const bool front = q <= lay.g.Q - 1 - q;
   roff = (int64_t)(front ? q : lay.g.Q - 1 - q) * G_TILE - (int64_t)ti * G_TILE;   // local row = i + roff
-  coff = front ? -(int64_t)ti * G_TILE : lay.g.W - lay.g.n;                           // local col = j + coff
+  coff = front ? -(int64_t)ti * G_TILE : shard_back(lay.g.W, lay.g.n);                           // local col = j + coff
   return true;
 }
 

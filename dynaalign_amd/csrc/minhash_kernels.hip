@@ -825,7 +825,7 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare(
     const int q = tid2.ti;
     const bool front = q <= fold_q - 1 - q;
     Iloc = (int64_t)(front ? q : fold_q - 1 - q) * K2_TILE - I0;
-    Jloc = front ? -I0 : fold_w - n;
+    Jloc = front ? -I0 : shard_back(fold_w, n);
   }
   if (I0 >= row_end || I0 >= n) return;
   if (!SYM && upper_only && J0 + K2_TILE <= I0) return;                     // tile entirely left of the diagonal
@@ -1383,6 +1383,126 @@ __device__ __forceinline__ void store_tile_f64(const uint16_t (&t)[FT][FT + 2], 
   }
 }
 
+// 64 x 64 tile of block b when the interior 128-tiles were taken by a 128 x 128 kernel: quarter (b & 3) of 128-tile b >> 2, the
+// T128 diagonal tiles first, then the last tile column when n is not a multiple of 128 (grid: leftover_blocks64)
+__device__ __forceinline__ TileId leftover_tile64(unsigned b, int n, int TB) {
+  const int T128 = (n + 127) >> 7, t = (int)(b >> 2), sub = (int)(b & 3);
+  const int ti128 = t < T128 ? t : t - T128, tj128 = t < T128 ? t : T128 - 1;
+  TileId o;
+  o.ti = 2 * ti128 + (sub >> 1); o.tj = 2 * tj128 + (sub & 1);
+  o.valid = o.ti <= o.tj && o.ti < TB && o.tj < TB;
+  return o;
+}
+__device__ __forceinline__ TileId decode_tile_xcd(unsigned b, int64_t per_xcd, int64_t ntiles, int TB) {
+  const int64_t L = (int64_t)(b & 7) * per_xcd + (b >> 3);
+  if (L >= ntiles) { TileId o; o.ti = o.tj = 0; o.valid = false; return o; }
+  return decode_tile(L, TB, TB, true);
+}
+static unsigned leftover_blocks64(int64_t n) {
+  const int T128 = (int)ceil_div(n, 128);
+  return (unsigned)(4 * (T128 + ((n & 127) ? T128 - 1 : 0)));
+}
+constexpr int ER_STRIDE = 272;   // bytes per staged tile row: 256 + 16 -- the lanes' 4-byte reads (row 2 ty, word tx) fall into 64 distinct banks
+// A 128 x 128 tile of uint16 codes staged in LDS (row stride ER_STRIDE) -> out[I0.., J0..] and its mirror image, float64.  Lane
+// (tx, ty) of the 16 x 16 lane grid owns rows 32 g + 2 ty + {0, 1} x columns 32 q + 2 tx + {0, 1} (k_mh_compare's epilogue):
+// direct rows go out as 16-byte stores of two adjacent columns, mirrored rows as 16-byte stores of two adjacent ROWS at one column.
+template <typename WIDEN>
+__device__ __forceinline__ void er_store_tile(const unsigned char *er_lds, WIDEN widen, double *__restrict__ out, int64_t ld, int64_t I0,
+                                              int64_t J0, int tx, int ty) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    double v0[8], v1[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w0 = *reinterpret_cast<const uint32_t *>(er_lds + (32 * g + 2 * ty) * ER_STRIDE + (32 * q + 2 * tx) * 2);
+      const uint32_t w1 = *reinterpret_cast<const uint32_t *>(er_lds + (32 * g + 2 * ty + 1) * ER_STRIDE + (32 * q + 2 * tx) * 2);
+      v0[2 * q] = widen(w0 & 0xffffu); v0[2 * q + 1] = widen(w0 >> 16);
+      v1[2 * q] = widen(w1 & 0xffffu); v1[2 * q + 1] = widen(w1 >> 16);
+    }
+    double *orow = out + (I0 + 32 * g + 2 * ty) * ld + (J0 + 2 * tx);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      nt_store2(orow + 32 * q, v0[2 * q], v0[2 * q + 1]);
+      nt_store2(orow + ld + 32 * q, v1[2 * q], v1[2 * q + 1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      nt_store2(out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 32 * g + 2 * ty), v0[c], v1[c]);
+  }
+}
+__device__ __forceinline__ bool expand_fast_takes(int ti128, int tj128, int n, int64_t ld, const void *out) {
+  return ti128 != tj128 && (ti128 + 1) * 128 <= n && (tj128 + 1) * 128 <= n && (ld & 1) == 0 &&
+         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+}
+
+// Gathered shards -> final matrix, interior off-diagonal 128 x 128 tiles (geom.tile = 128: a tile lives in ONE rank's block):
+// 128 row pieces of 128 codes are staged in LDS with 16-byte loads (uint16 blocks) or 8 low bytes + the bit planes' byte per
+// 8 columns (packed blocks), then er_store_tile writes both halves with 16-byte streaming stores -- the pattern that reaches
+// 5.7-6.4 TB/s in k_expand_rows (the 64 x 64 LDS-transpose kernels below: 3.4-3.9 TB/s; they keep diagonal / border tiles).
+template <bool IS_NW, bool PACKED>
+__global__ __launch_bounds__(256, 4) void k_finalize_rows(const void *__restrict__ G_v, int64_t ld_g_or_block_bytes, ShardGeom geom, int nhi,
+                                                          int n_hash, int tab_entries, double *__restrict__ out, int64_t ld, int T128,
+                                                          int64_t ntiles, int64_t per_xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char er_lds[];   // 128 x ER_STRIDE tile, then the value table (MH)
+  double *tab = reinterpret_cast<double *>(er_lds + 128 * ER_STRIDE);
+  const int n = (int)geom.n;
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= ntiles) return;
+  const TileId tt = decode_tile(L, T128, T128, true);
+  if (!tt.valid || !expand_fast_takes(tt.ti, tt.tj, n, ld, out)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tx = ((wave & 1) << 3) + (lane & 7), ty = ((wave >> 1) << 3) + (lane >> 3);
+  const int64_t I0 = (int64_t)tt.ti * 128, J0 = (int64_t)tt.tj * 128;
+  const int tr = tt.ti, q_loc = tr / geom.world, owner = tr - q_loc * geom.world;
+  const bool front = q_loc <= geom.Q - 1 - q_loc;
+  const int64_t lrow0 = (int64_t)(front ? q_loc : geom.Q - 1 - q_loc) * 128;               // row inside the owner's block
+  const int64_t col0 = (front ? -(int64_t)tr * 128 : shard_back(geom.W, geom.n)) + J0;     // a multiple of 8
+  const int unit = tid & 15, row0 = tid >> 4;
+  uint4 st[8];
+  if (!PACKED) {
+    const uint16_t *G = static_cast<const uint16_t *>(G_v);
+    const int64_t ld_g = ld_g_or_block_bytes;
+    const uint16_t *src = G + ((int64_t)owner * geom.rows + lrow0 + row0) * ld_g + col0 + 8 * unit;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st[q] = *reinterpret_cast<const uint4 *>(src + (int64_t)(16 * q) * ld_g);
+  } else {
+    const uint8_t *blk = static_cast<const uint8_t *>(G_v) + (int64_t)owner * ld_g_or_block_bytes;
+    const int64_t W = geom.W, groups = W >> 3, rows = geom.rows, col = col0 + 8 * unit;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t row = lrow0 + row0 + 16 * q;
+      const uint2 lo = *reinterpret_cast<const uint2 *>(blk + row * W + col);
+      uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < nhi; ++k) {
+        const uint32_t b = blk[rows * W + ((int64_t)k * rows + row) * groups + (col >> 3)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hi[e] |= ((b >> e) & 1u) << (8 + k);
+      }
+      st[q].x = ((lo.x & 255u) | hi[0]) | ((((lo.x >> 8) & 255u) | hi[1]) << 16);
+      st[q].y = (((lo.x >> 16) & 255u) | hi[2]) | (((lo.x >> 24) | hi[3]) << 16);
+      st[q].z = ((lo.y & 255u) | hi[4]) | ((((lo.y >> 8) & 255u) | hi[5]) << 16);
+      st[q].w = (((lo.y >> 16) & 255u) | hi[6]) | (((lo.y >> 24) | hi[7]) << 16);
+    }
+  }
+  if (!IS_NW)
+    for (int e = tid; e < tab_entries; e += 256) tab[e] = (double)e / (double)n_hash;              // src/minHash.cpp:174
+#pragma unroll
+  for (int q = 0; q < 8; ++q) *reinterpret_cast<uint4 *>(er_lds + (row0 + 16 * q) * ER_STRIDE + unit * 16) = st[q];
+  __syncthreads();
+  auto widen = [&](uint32_t x) -> double {
+    if (!IS_NW) return tab_entries ? tab[x] : (double)x / (double)n_hash;
+    const uint32_t ln = x & 255u;
+    if (ln == 0) return __longlong_as_double(0xFFF8000000000000ULL);     // 0/0 as on the reference's host
+    return (double)(x >> 8) / (double)ln;                                // src/pairwiseSeqAlign.cpp:311
+  };
+  er_store_tile(er_lds, widen, out, ld, I0, J0, tx, ty);
+}
+// the interior tiles go to k_finalize_rows when the geometry allows it; the 64 x 64 kernels then visit only what is left
+static bool finalize_rows_ok(const ShardGeom &geom, const void *d_g, int64_t ld_g, const double *d_out, int64_t ld, bool packed) {
+  return geom.tile == 128 && geom.n >= 256 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(d_g) & 15) == 0 && (packed || (ld_g & 7) == 0) && !getenv("DYNAALIGN_FINALIZE_NO_FAST");
+}
+
 // Gathered shards -> final matrix.  G holds, for every rank p, its folded local block
 // (ShardGeom); out[i][j] = widen(G[entry of (min(i,j), max(i,j))]).  One workgroup per 64 x 64
 // tile on or above the diagonal, enumerated like the compare kernel's tiles (bands of 8 tile rows,
@@ -1397,14 +1517,12 @@ __device__ __forceinline__ void store_tile_f64(const uint16_t (&t)[FT][FT + 2], 
 template <bool IS_NW>
 __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__restrict__ G, int64_t ld_g, ShardGeom geom,
                                                           int n_hash, double *__restrict__ out, int64_t ld, int TB,
-                                                          int64_t ntiles, int64_t per_xcd) {
+                                                          int64_t ntiles, int64_t per_xcd, int skip_fast) {
   constexpr int FT = 64, TABLE = 2048;
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ double ratio[IS_NW ? 1 : TABLE];
   const int n = (int)geom.n;
-  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (L >= ntiles) return;
-  const TileId tt = decode_tile(L, TB, TB, true);
+  const TileId tt = skip_fast ? leftover_tile64(blockIdx.x, n, TB) : decode_tile_xcd(blockIdx.x, per_xcd, ntiles, TB);
   if (!tt.valid) return;
   const int i0 = tt.ti * FT, j0 = tt.tj * FT;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
@@ -1423,7 +1541,7 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
   const int q = tr / geom.world, owner = tr - q * geom.world;
   const bool front = q <= geom.Q - 1 - q;
   const int64_t lrow0 = (int64_t)owner * geom.rows + (int64_t)(front ? q : geom.Q - 1 - q) * tile + (i0 - tr * tile);
-  const int64_t coff = front ? -(int64_t)tr * tile : geom.W - geom.n;
+  const int64_t coff = front ? -(int64_t)tr * tile : shard_back(geom.W, geom.n);
   const uint16_t *src = G + lrow0 * ld_g + coff + j0 + tx;
   const int j = j0 + tx;
   for (int r = ty; r < FT; r += 4) {
@@ -1439,26 +1557,13 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
 // 64 x 64 output tiles on or above the diagonal in the banded XCD order of k_finalize_sharded, gathered through LDS so that
 // the mirrored half is written as row pieces too.  Single-copy strings are numbered in input order, so most of a row's
 // gather hits consecutive table columns; the multi-copy ones sit in the first few KiB of every table row.
-__device__ __forceinline__ bool expand_fast_takes(int ti128, int tj128, int n, int64_t ld, const void *out);
 template <bool F64, bool IS_NW, int FT>
 __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                        int n, int n_hash, void *__restrict__ out_v, int64_t ld, int TB,
                                                        int64_t ntiles, int64_t per_xcd, int skip_fast) {
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ int32_t ur[FT], uc[FT];
-  TileId tt;
-  if (skip_fast) {
-    // only what k_expand_rows leaves (FT = 64): block b -> quarter (b & 3) of 128-tile b >> 2, the T128 diagonal tiles first, then
-    // the last tile column when n is not a multiple of 128
-    const int T128 = (n + 127) >> 7, t = blockIdx.x >> 2, sub = blockIdx.x & 3;
-    const int ti128 = t < T128 ? t : t - T128, tj128 = t < T128 ? t : T128 - 1;
-    tt.ti = 2 * ti128 + (sub >> 1); tt.tj = 2 * tj128 + (sub & 1);
-    tt.valid = tt.ti <= tt.tj && tt.ti < TB && tt.tj < TB;
-  } else {
-    const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (L >= ntiles) return;
-    tt = decode_tile(L, TB, TB, true);
-  }
+  const TileId tt = skip_fast ? leftover_tile64(blockIdx.x, n, TB) : decode_tile_xcd(blockIdx.x, per_xcd, ntiles, TB);
   if (!tt.valid) return;
   const int i0 = tt.ti * FT, j0 = tt.tj * FT;
   constexpr int RS = 256 / FT;
@@ -1508,10 +1613,6 @@ __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restric
 //                      loads -> LDS), every lane then owns an 8 x 8 block exactly like k_mh_compare's epilogue: no transpose, the
 //                      mirrored 16-byte store of rows r, r+1 at one column uses values the lane already holds.
 // The tiles they take (expand_fast_takes) are skipped by k_expand_unique, which keeps diagonal and border tiles.
-__device__ __forceinline__ bool expand_fast_takes(int ti128, int tj128, int n, int64_t ld, const void *out) {
-  return ti128 != tj128 && (ti128 + 1) * 128 <= n && (tj128 + 1) * 128 <= n && (ld & 1) == 0 &&
-         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-}
 constexpr int GC_THREADS = 1024;
 // one resident workgroup per CU walks the unique rows r = blockIdx.x, + gridDim.x, ...: the NEXT row is already on its way into
 // registers while the current one is gathered out of LDS (U <= 65536 -> at most 8 16-byte units per thread)
@@ -1553,7 +1654,6 @@ __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *_
 #undef GC_FETCH
 }
 
-constexpr int ER_STRIDE = 272;   // bytes per staged tile row: 256 + 16 -- the lanes' 4-byte reads (row 2 ty, word tx) fall into 64 distinct banks
 template <bool IS_NW>
 __global__ __launch_bounds__(256, 4) void k_expand_rows(const uint16_t *__restrict__ F, int64_t ld_f, const int32_t *__restrict__ uidx,
                                                         int n, int n_hash, int tab_stride, int tab_entries, double *__restrict__ out,
@@ -1590,26 +1690,7 @@ __global__ __launch_bounds__(256, 4) void k_expand_rows(const uint16_t *__restri
     if (IS_NW) return tab[(x >> 8) * (uint32_t)tab_stride + (x & 255u)];
     return tab[x];
   };
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    double v0[8], v1[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t w0 = *reinterpret_cast<const uint32_t *>(er_lds + (32 * g + 2 * ty) * ER_STRIDE + (32 * q + 2 * tx) * 2);
-      const uint32_t w1 = *reinterpret_cast<const uint32_t *>(er_lds + (32 * g + 2 * ty + 1) * ER_STRIDE + (32 * q + 2 * tx) * 2);
-      v0[2 * q] = widen(w0 & 0xffffu); v0[2 * q + 1] = widen(w0 >> 16);
-      v1[2 * q] = widen(w1 & 0xffffu); v1[2 * q + 1] = widen(w1 >> 16);
-    }
-    double *orow = out + (I0 + 32 * g + 2 * ty) * ld + (J0 + 2 * tx);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      nt_store2(orow + 32 * q, v0[2 * q], v0[2 * q + 1]);
-      nt_store2(orow + ld + 32 * q, v1[2 * q], v1[2 * q + 1]);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      nt_store2(out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 32 * g + 2 * ty), v0[c], v1[c]);
-  }
+  er_store_tile(er_lds, widen, out, ld, I0, J0, tx, ty);
 }
 
 // device bytes of the column-gathered table the two-pass expansion wants (0: the shape is not covered, pass NULL)
@@ -1669,10 +1750,7 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   else if (after_gather) DA_HIP_TRY(hipEventRecord(after_gather, stream));
   if (after_rows) DA_HIP_TRY(hipEventRecord(after_rows, stream));
   const int skip_fast = fast ? 1 : 0;
-  if (fast) {   // the 64 x 64 kernel then only visits the diagonal 128-tiles and the border column
-    const int T128 = (int)ceil_div(n, 128);
-    grid.x = (unsigned)(4 * (T128 + ((n & 127) ? T128 - 1 : 0)));
-  }
+  if (fast) grid.x = leftover_blocks64(n);   // the 64 x 64 kernel then only visits the diagonal 128-tiles and the border column
 #define DA_EXP(F, W, T) hipLaunchKernelGGL((k_expand_unique<F, W, T>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd, skip_fast)
   if (ft == 128) {
     if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 128); else DA_EXP(true, false, 128); }
@@ -1694,11 +1772,23 @@ int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &
   const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   const int64_t per_xcd = ceil_div(tiles, 8);
-  const dim3 grid((unsigned)(per_xcd * 8));
+  dim3 grid((unsigned)(per_xcd * 8));
+  const bool fast = finalize_rows_ok(geom, d_g, ld_g, d_out, ld, false);
+  if (fast) {
+    const int T128 = (int)ceil_div(geom.n, 128);
+    const int64_t t128 = (int64_t)T128 * (T128 + 1) / 2, px = ceil_div(t128, 8);
+    const int entries = (!is_nw && n_hash + 1 <= 2048) ? n_hash + 1 : 0;
+    const size_t lds = 128 * ER_STRIDE + (size_t)entries * 8;
+    if (is_nw) hipLaunchKernelGGL((k_finalize_rows<true, false>), dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_g, ld_g, geom, 0, n_hash, entries,
+                                  d_out, ld, T128, t128, px);
+    else hipLaunchKernelGGL((k_finalize_rows<false, false>), dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_g, ld_g, geom, 0, n_hash, entries,
+                            d_out, ld, T128, t128, px);
+    grid.x = leftover_blocks64(geom.n);
+  }
   if (is_nw)
-    hipLaunchKernelGGL(k_finalize_sharded<true>, grid, dim3(256), 0, stream, d_g, ld_g, geom, n_hash, d_out, ld, TB, tiles, per_xcd);
+    hipLaunchKernelGGL(k_finalize_sharded<true>, grid, dim3(256), 0, stream, d_g, ld_g, geom, n_hash, d_out, ld, TB, tiles, per_xcd, fast ? 1 : 0);
   else
-    hipLaunchKernelGGL(k_finalize_sharded<false>, grid, dim3(256), 0, stream, d_g, ld_g, geom, n_hash, d_out, ld, TB, tiles, per_xcd);
+    hipLaunchKernelGGL(k_finalize_sharded<false>, grid, dim3(256), 0, stream, d_g, ld_g, geom, n_hash, d_out, ld, TB, tiles, per_xcd, fast ? 1 : 0);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
@@ -1739,14 +1829,12 @@ __global__ __launch_bounds__(256) void k_pack_shard(const uint16_t *__restrict__
 // k_finalize_sharded reading packed blocks (MH only): G = world blocks of block_bytes each
 __global__ __launch_bounds__(256) void k_finalize_packed(const uint8_t *__restrict__ G, int64_t block_bytes, ShardGeom geom,
                                                          int nhi, int n_hash, double *__restrict__ out, int64_t ld, int TB,
-                                                         int64_t ntiles, int64_t per_xcd) {
+                                                         int64_t ntiles, int64_t per_xcd, int skip_fast) {
   constexpr int FT = 64, TABLE = 2048;
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ double ratio[TABLE];
   const int n = (int)geom.n;
-  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (L >= ntiles) return;
-  const TileId tt = decode_tile(L, TB, TB, true);
+  const TileId tt = skip_fast ? leftover_tile64(blockIdx.x, n, TB) : decode_tile_xcd(blockIdx.x, per_xcd, ntiles, TB);
   if (!tt.valid) return;
   const int i0 = tt.ti * FT, j0 = tt.tj * FT;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
@@ -1759,7 +1847,7 @@ __global__ __launch_bounds__(256) void k_finalize_packed(const uint8_t *__restri
   const int q = tr / geom.world, owner = tr - q * geom.world;
   const bool front = q <= geom.Q - 1 - q;
   const int64_t lrow0 = (int64_t)(front ? q : geom.Q - 1 - q) * tile + (i0 - tr * tile);   // row inside the owner's block
-  const int64_t coff = front ? -(int64_t)tr * tile : geom.W - geom.n;
+  const int64_t coff = front ? -(int64_t)tr * tile : shard_back(geom.W, geom.n);
   const uint8_t *blk = G + (int64_t)owner * block_bytes;
   const int64_t W = geom.W, groups = W >> 3, rows = geom.rows;
   const int j = j0 + tx;
@@ -1802,8 +1890,19 @@ int launch_finalize_packed(const uint8_t *d_g, const ShardGeom &geom, int value_
   const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   const int64_t per_xcd = ceil_div(tiles, 8);
-  hipLaunchKernelGGL(k_finalize_packed, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, stream, d_g, shard_packed_bytes(geom, value_bits),
-                     geom, value_bits > 8 ? value_bits - 8 : 0, n_hash, d_out, ld, TB, tiles, per_xcd);
+  const int nhi = value_bits > 8 ? value_bits - 8 : 0;
+  unsigned blocks = (unsigned)(per_xcd * 8);
+  const bool fast = finalize_rows_ok(geom, d_g, 0, d_out, ld, true);
+  if (fast) {
+    const int T128 = (int)ceil_div(geom.n, 128);
+    const int64_t t128 = (int64_t)T128 * (T128 + 1) / 2, px = ceil_div(t128, 8);
+    const int entries = n_hash + 1 <= 2048 ? n_hash + 1 : 0;
+    hipLaunchKernelGGL((k_finalize_rows<false, true>), dim3((unsigned)(px * 8)), dim3(256), 128 * ER_STRIDE + (size_t)entries * 8, stream, d_g,
+                       shard_packed_bytes(geom, value_bits), geom, nhi, n_hash, entries, d_out, ld, T128, t128, px);
+    blocks = leftover_blocks64(geom.n);
+  }
+  hipLaunchKernelGGL(k_finalize_packed, dim3(blocks), dim3(256), 0, stream, d_g, shard_packed_bytes(geom, value_bits),
+                     geom, nhi, n_hash, d_out, ld, TB, tiles, per_xcd, fast ? 1 : 0);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

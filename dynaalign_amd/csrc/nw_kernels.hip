@@ -230,7 +230,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
     {  // folded shard layout (ShardGeom, tile = 128): units u and Q-1-u share a stored unit row
       const bool front = u <= fold_q - 1 - u;
       row_shift = (int64_t)(front ? u : fold_q - 1 - u) * 128 + (int64_t)(q64 & 1) * K3_TILE - (int64_t)ti * K3_TILE;
-      col_shift = front ? -(int64_t)gu * 128 : fold_w - n;
+      col_shift = front ? -(int64_t)gu * 128 : shard_back(fold_w, n);
     }
   } else {
     // row-block request: tile row rt (inside the block) x every tile column tc.

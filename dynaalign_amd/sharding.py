@@ -33,8 +33,8 @@ class Plan:
 
     Folded layout (csrc/da_common.hpp ShardGeom): rank p owns tile rows t = q*world + p, q = 0..Q-1, and only
     their part right of the diagonal is valid, so local tile rows q and Q-1-q share one stored tile row of
-    width W = n + world*tile (rounded up to 8): the first left-aligned from its diagonal tile, the second
-    right-aligned.  A block is local_rows x width -- half of a full-width row block."""
+    width W = ceil8(n) + world*tile: the first left-aligned from its diagonal tile, the second starting at column
+    world*tile (both on a multiple of 8 columns).  A block is local_rows x width -- half of a full-width row block."""
 
     def __init__(self, n, rank, world, tile=MH_TILE):
         self.n, self.rank, self.world, self.tile = int(n), int(rank), int(world), int(tile)
@@ -42,7 +42,8 @@ class Plan:
         self.local_tiles = -(-self.tiles // self.world)            # tile rows per rank (Q, padded)
         self.stored_tiles = (self.local_tiles + 1) // 2            # after folding (Qh)
         self.local_rows = self.stored_tiles * self.tile
-        self.width = -(-(self.n + self.world * self.tile) // 8) * 8
+        self.width = -(-self.n // 8) * 8 + self.world * self.tile
+        self.back = self.world * self.tile                         # local column of global column 0 in a back-aligned row (width - ceil8(n))
 
     def owner(self, i):
         """rank owning global row i"""
@@ -55,7 +56,7 @@ class Plan:
         front = q <= self.local_tiles - 1 - q
         f = q if front else self.local_tiles - 1 - q
         row = f * self.tile + i % self.tile
-        col = j - t * self.tile if front else self.width - self.n + j
+        col = j - t * self.tile if front else self.back + j
         return t % self.world, row, col
 
     def gathered_row(self, i):
