@@ -48,14 +48,14 @@ namespace {
 // Large device buffers are kept for the next call instead of going back to the driver: hipMalloc / hipFree of the
 // 80 GB result buffer cost up to 3.2 s every other call on MI355X (profiles/r02_b_host_path_trace.txt) -- more than the
 // 1.5 s the PCIe copy of the result takes -- and clusterbreak calls sim_fn again and again.  Per device up to MAX_PARKED
-// buffers totalling at most 45 % of the device's memory are parked (one call of the duplicate-collapsing routes uses four:
+// buffers of >= 1 MiB totalling at most 45 % of the device's memory are parked (one call of the duplicate-collapsing routes uses four:
 // plan, table, gathered table, plane workspace); a request takes the smallest parked buffer that fits it and is at most
 // twice its size (a 300 MB request must not walk away with the 9 GB buffer the next allocation of the same call wants);
 // when room is needed the smallest parked buffers go first (cheapest to allocate again).  da_release_device_memory()
 // returns everything to the driver, and so does an allocation of ours that would otherwise fail.
 struct BigCache {
-  static constexpr size_t MIN_BYTES = (size_t)256 << 20;
-  static constexpr int MAX_PARKED = 8;
+  static constexpr size_t MIN_BYTES = (size_t)1 << 20;     // (hipFree synchronises the device: even the 10 MB plan is worth keeping)
+  static constexpr int MAX_PARKED = 16;
   struct Ent { int dev; void *p; size_t bytes; };
   std::mutex m;
   std::vector<Ent> parked;
