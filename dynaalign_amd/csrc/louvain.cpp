@@ -61,6 +61,29 @@ struct Mt19937 {   // ISO C++ [rand.predef] mt19937, restated (std::shuffle / un
   }
 };
 
+// Host threads for the data-parallel parts (CSR build, strengths, aggregation) and for the speculative neighbourhood scans of
+// the local-moving passes.  Nothing the function returns depends on the count (DYNAALIGN_LOUVAIN_THREADS overrides it; 1 = serial).
+int host_threads(int64_t work_items) {
+  int t = (int)std::min<int64_t>(16, std::max<int64_t>(1, work_items / 2000000));
+  if (const char *e = getenv("DYNAALIGN_LOUVAIN_THREADS")) t = std::max(1, atoi(e));
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw > 0 && (unsigned)t > hw) t = (int)hw;
+  return t;
+}
+template <typename F> void run_threads(int nthreads, F body) {   // body(thread index)
+  if (nthreads <= 1) { body(0); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t) th.emplace_back(body, t);
+  for (auto &x : th) x.join();
+}
+// vertex range [v0, v1) of thread t when the vertices are cut into ranges of roughly equal adjacency volume
+void volume_range(const std::vector<int64_t> &ptr, int64_t n, int t, int nthreads, int64_t *v0, int64_t *v1) {
+  const int64_t total = ptr[(size_t)n];
+  const int64_t lo = total * t / nthreads, hi = total * (t + 1) / nthreads;
+  *v0 = t == 0 ? 0 : std::lower_bound(ptr.begin(), ptr.end() - 1, lo) - ptr.begin();
+  *v1 = (t + 1 == nthreads) ? n : std::lower_bound(ptr.begin(), ptr.end() - 1, hi) - ptr.begin();
+}
+
 // symmetric CSR without self-loops; self-loop weights kept per vertex
 struct Graph {
   int32_t n = 0;
@@ -70,6 +93,21 @@ struct Graph {
   std::vector<double> loop;     // self-loop weight per vertex (0 if none)
   double total = 0.0;           // 2m = sum of strengths
 };
+
+// k[v] = 2 loop(v) + sum of v's edge weights in canonical order; vertices are independent, a few threads share them
+void strengths(const Graph &g, std::vector<double> &k) {
+  k.assign((size_t)g.n, 0.0);
+  const int nthreads = host_threads((int64_t)g.adj.size());
+  run_threads(nthreads, [&](int t) {
+    int64_t v0, v1;
+    volume_range(g.ptr, g.n, t, nthreads, &v0, &v1);
+    for (int64_t v = v0; v < v1; ++v) {
+      double s = 2.0 * g.loop[(size_t)v];
+      for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) s += g.w[(size_t)q];
+      k[(size_t)v] = s;
+    }
+  });
+}
 
 // (i, j, w) list -> canonical Graph.  Entries with i == j are loops; (i, j) and (j, i) are the same edge;
 // repeated entries are summed.
@@ -86,34 +124,32 @@ int build_graph(int64_t n, int64_t m, const int32_t *ei, const int32_t *ej, cons
   for (int64_t v = 0; v < n; ++v) g.ptr[(size_t)v + 1] += g.ptr[(size_t)v];
   g.adj.resize((size_t)g.ptr[(size_t)n]);
   g.w.resize((size_t)g.ptr[(size_t)n]);
-  std::vector<int64_t> fill(g.ptr.begin(), g.ptr.end() - 1);
   // loops: summed in ascending order of their position in a canonical (sorted) view -- a vertex's loops are
   // gathered first, sorted, then added, so the sum does not depend on arrival order
   std::vector<std::pair<int32_t, double>> loops;
-  for (int64_t e = 0; e < m; ++e) {
-    const int32_t a = ei[e], b = ej[e];
-    if (a == b) { loops.emplace_back(a, ew[e]); continue; }
-    g.adj[(size_t)fill[(size_t)a]] = b; g.w[(size_t)fill[(size_t)a]++] = ew[e];
-    g.adj[(size_t)fill[(size_t)b]] = a; g.w[(size_t)fill[(size_t)b]++] = ew[e];
-  }
+  for (int64_t e = 0; e < m; ++e)
+    if (ei[e] == ej[e]) loops.emplace_back(ei[e], ew[e]);
   std::sort(loops.begin(), loops.end());
   for (const auto &l : loops) g.loop[(size_t)l.first] += l.second;
-  // sort each neighbour list by (id, weight) -- vertices are independent, so a few host threads share them (the result does
-  // not depend on the thread count) -- then merge duplicate entries, sequentially and only if there are any
+  // fill + sort each neighbour list by (id, weight): thread t owns a contiguous vertex range of roughly equal adjacency volume,
+  // scans the whole edge list and places the endpoints that fall in its range (random writes stay inside the thread's slice),
+  // then sorts its lists -- vertices are independent and the sort canonicalises the order, so the result does not depend on the
+  // thread count.  Duplicate entries are merged afterwards, sequentially and only if there are any.
   {
-    int nthreads = (int)std::min<int64_t>(16, std::max<int64_t>(1, (int64_t)g.adj.size() / 2000000));
-    if (const char *e = getenv("DYNAALIGN_LOUVAIN_THREADS")) nthreads = std::max(1, atoi(e));
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw > 0 && (unsigned)nthreads > hw) nthreads = (int)hw;
+    const int nthreads = host_threads((int64_t)g.adj.size());
     std::atomic<int> any_dup(0);
+    std::vector<int64_t> fill(g.ptr.begin(), g.ptr.end() - 1);
     auto work = [&](int t) {
+      int64_t v0, v1;
+      volume_range(g.ptr, n, t, nthreads, &v0, &v1);
+      for (int64_t e = 0; e < m; ++e) {
+        const int32_t a = ei[e], b = ej[e];
+        if (a == b) continue;
+        if (a >= v0 && a < v1) { g.adj[(size_t)fill[(size_t)a]] = b; g.w[(size_t)fill[(size_t)a]++] = ew[e]; }
+        if (b >= v0 && b < v1) { g.adj[(size_t)fill[(size_t)b]] = a; g.w[(size_t)fill[(size_t)b]++] = ew[e]; }
+      }
       std::vector<std::pair<int32_t, double>> tmp;
       bool dup = false;
-      // contiguous ranges of roughly equal adjacency volume
-      const int64_t total_adj = (int64_t)g.adj.size();
-      const int64_t lo = total_adj * t / nthreads, hi = total_adj * (t + 1) / nthreads;
-      int64_t v0 = std::lower_bound(g.ptr.begin(), g.ptr.end() - 1, lo) - g.ptr.begin();
-      int64_t v1 = (t + 1 == nthreads) ? n : std::lower_bound(g.ptr.begin(), g.ptr.end() - 1, hi) - g.ptr.begin();
       for (int64_t v = v0; v < v1; ++v) {
         const int64_t b = g.ptr[(size_t)v], e = g.ptr[(size_t)v + 1];
         tmp.clear();
@@ -127,12 +163,7 @@ int build_graph(int64_t n, int64_t m, const int32_t *ei, const int32_t *ej, cons
       }
       if (dup) any_dup.store(1);
     };
-    if (nthreads <= 1) work(0);
-    else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
-      for (auto &x : th) x.join();
-    }
+    run_threads(nthreads, work);
     if (any_dup.load()) {
       int64_t out = 0;
       std::vector<int64_t> nptr((size_t)n + 1, 0);
@@ -151,11 +182,9 @@ int build_graph(int64_t n, int64_t m, const int32_t *ei, const int32_t *ej, cons
     }
   }
   g.total = 0.0;
-  for (int64_t v = 0; v < n; ++v) {
-    double k = 2.0 * g.loop[(size_t)v];
-    for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) k += g.w[(size_t)q];
-    g.total += k;
-  }
+  std::vector<double> k;
+  strengths(g, k);
+  for (int64_t v = 0; v < n; ++v) g.total += k[(size_t)v];     // (sequential: the order of this sum is part of the result)
   return DA_OK;
 }
 
@@ -181,19 +210,52 @@ double modularity_of(const Graph &g, const std::vector<int32_t> &comm, double re
 
 // One level: local moving on g.  comm (out): community per vertex, renumbered 0..nc-1 in order of first
 // appearance by vertex.  Returns the number of communities; *moved says whether anything changed.
+//
+// The decisions are strictly sequential (vertex i sees every move made before it), but what dominates a pass on a dense graph
+// -- scanning a vertex's adjacency and summing the edge weights per neighbouring community (2 900 entries per vertex at
+// N = 100k, thresh_p = .8) -- only depends on the communities of the vertex's NEIGHBOURS.  After the first pass few vertices
+// move (3 371, 2 064, ... of 100 000), so helper threads run those scans AHEAD of the deciding thread (a window of positions in
+// the visiting order) and the deciding thread uses a scan iff no neighbour of the vertex has moved since the scan started
+// (it stamps the neighbours of every vertex it moves with a move counter); otherwise it scans itself.  A scan is the same
+// canonical-order sum whoever runs it, so the membership is bit-identical to the one-thread run whatever the timing; when most
+// scans of a pass turn out stale (the first pass: everything moves) the helpers are parked for the rest of the pass.
+struct Scan {                       // neighbouring communities of one vertex in order of first appearance + weight to each
+  std::vector<int32_t> cid;
+  std::vector<double> cw;
+  uint64_t epoch = 0;               // move counter read before the first community lookup
+};
+struct ScanScratch {
+  std::vector<double> wto;
+  std::vector<char> seen;
+  explicit ScanScratch(size_t n) : wto(n, 0.0), seen(n, 0) {}
+};
+inline void scan_vertex(const Graph &g, const int32_t *comm, int32_t v, ScanScratch &sc, Scan &out) {
+  out.cid.clear();
+  out.cw.clear();
+  for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) {
+    const int32_t c = __atomic_load_n(&comm[(size_t)g.adj[(size_t)q]], __ATOMIC_RELAXED);
+    if (!sc.seen[(size_t)c]) { sc.seen[(size_t)c] = 1; out.cid.push_back(c); }
+    sc.wto[(size_t)c] += g.w[(size_t)q];
+  }
+  out.cw.resize(out.cid.size());
+  for (size_t t = 0; t < out.cid.size(); ++t) {
+    const int32_t c = out.cid[t];
+    out.cw[t] = sc.wto[(size_t)c];
+    sc.wto[(size_t)c] = 0.0;
+    sc.seen[(size_t)c] = 0;
+  }
+}
+
 int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<int32_t> &comm, bool *moved) {
   const int32_t n = g.n;
   comm.resize((size_t)n);
   std::iota(comm.begin(), comm.end(), 0);
   // per community: tot = sum of member strengths, in = internal weight (every internal edge twice, loops twice) -- both
   // kept up to date move by move, so the modularity after a pass costs O(n) instead of another sweep over all edges
-  std::vector<double> k((size_t)n), tot((size_t)n), in((size_t)n);
-  for (int32_t v = 0; v < n; ++v) {
-    double s = 2.0 * g.loop[(size_t)v];
-    for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) s += g.w[(size_t)q];
-    k[(size_t)v] = tot[(size_t)v] = s;
-    in[(size_t)v] = 2.0 * g.loop[(size_t)v];
-  }
+  std::vector<double> k, tot, in((size_t)n);
+  strengths(g, k);
+  tot = k;
+  for (int32_t v = 0; v < n; ++v) in[(size_t)v] = 2.0 * g.loop[(size_t)v];
   auto modularity_now = [&]() {
     double Q = 0.0;
     for (int32_t c = 0; c < n; ++c)
@@ -207,50 +269,145 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
     const int32_t j = i + (int32_t)(rng.next() % (uint32_t)(n - i));
     std::swap(order[(size_t)i], order[(size_t)j]);
   }
-  std::vector<double> wto((size_t)n, 0.0);                    // weight from the current vertex to community c
-  std::vector<char> seen((size_t)n, 0);
-  std::vector<int32_t> touched;                               // neighbouring communities in order of first appearance
   *moved = false;
   const double m2 = g.total;
   if (m2 <= 0.0) return n;
+
+  // ---- helpers (only worth it on big graphs)
+  const bool debug = getenv("DYNAALIGN_LOUVAIN_DEBUG") != nullptr;
+  const int nthreads = host_threads((int64_t)g.adj.size());
+  const int nhelp = nthreads - 1;
+  constexpr int32_t WINDOW = 512, WINDOW_MIN = 32;            // positions of the visiting order the helpers may run ahead: the ring /
+  std::atomic<int32_t> window(WINDOW_MIN);                    // what the decider currently allows (few moves -> far ahead; many -> close)
+  std::vector<Scan> ring(nhelp > 0 ? (size_t)WINDOW : 1);
+  std::vector<std::atomic<uint8_t>> state(nhelp > 0 ? (size_t)n : 0);   // per position: 0 free, 1 helper scanning, 2 helper done, 3 decider's own
+  std::vector<uint64_t> stamp(nhelp > 0 ? (size_t)n : 0, 0);  // per vertex: move counter when a neighbour last moved (decider only)
+  std::atomic<uint64_t> epoch(0);                             // moves so far
+  std::atomic<int32_t> decided(0), next_scan(0);              // positions finished by the decider / handed to helpers
+  std::atomic<int> phase(0);                                  // 0 parked, 1 scanning, 2 quit
+  std::atomic<int> pass_id(0), active(0);                     // pass counter; helpers inside their scanning loop
+  std::atomic<uint64_t> dbg_ns(0), dbg_cnt(0);                // (debug: time inside the helpers' scans)
+  int32_t *comm_p = comm.data();
+  std::vector<std::thread> helpers;
+  for (int h = 0; h < nhelp; ++h)
+    helpers.emplace_back([&]() {
+      ScanScratch sc((size_t)n);
+      int done_pass = 0;
+      for (;;) {
+        int ph;
+        while ((ph = phase.load(std::memory_order_acquire)) != 2 && !(ph == 1 && pass_id.load(std::memory_order_acquire) != done_pass))
+          std::this_thread::yield();
+        if (ph == 2) return;
+        active.fetch_add(1, std::memory_order_acq_rel);
+        const int cur = pass_id.load(std::memory_order_acquire);
+        while (phase.load(std::memory_order_acquire) == 1 && pass_id.load(std::memory_order_acquire) == cur) {
+          const int32_t i = next_scan.fetch_add(1, std::memory_order_relaxed);
+          if (i >= n) break;
+          bool open = true;                                   // the ring slot of position i is free once position i - WINDOW is decided
+          while (decided.load(std::memory_order_acquire) + window.load(std::memory_order_relaxed) <= i) {
+            if (phase.load(std::memory_order_acquire) != 1) { open = false; break; }
+            std::this_thread::yield();
+          }
+          if (!open) break;                                   // parked mid-pass: position i stays free, the decider takes it
+          uint8_t expect = 0;
+          if (!state[(size_t)i].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) continue;   // the decider took it
+          Scan &slot = ring[(size_t)(i % WINDOW)];
+          slot.epoch = epoch.load(std::memory_order_acquire);
+          if (!debug) scan_vertex(g, comm_p, order[(size_t)i], sc, slot);
+          else {
+            const auto t0 = std::chrono::steady_clock::now();
+            scan_vertex(g, comm_p, order[(size_t)i], sc, slot);
+            dbg_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+            dbg_cnt.fetch_add(1);
+          }
+          state[(size_t)i].store(2, std::memory_order_release);
+        }
+        done_pass = cur;
+        active.fetch_sub(1, std::memory_order_acq_rel);
+      }
+    });
+
+  ScanScratch my_sc((size_t)n);
+  Scan my_scan;
   double q_prev = modularity_now();
   for (;;) {
-    int64_t changed = 0;
+    int64_t changed = 0, used = 0, stale = 0, used_blk = 0, stale_blk = 0;
+    const auto t_pass = std::chrono::steady_clock::now();
+    bool use_scans = nhelp > 0;
+    if (nhelp > 0) {                                          // open the pass for the helpers (none of them is scanning any more)
+      while (active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+      for (int32_t i = 0; i < n; ++i) state[(size_t)i].store(0, std::memory_order_relaxed);
+      decided.store(0, std::memory_order_relaxed);
+      next_scan.store(0, std::memory_order_relaxed);
+      window.store(WINDOW_MIN, std::memory_order_relaxed);
+      pass_id.fetch_add(1, std::memory_order_acq_rel);
+      phase.store(1, std::memory_order_release);
+    }
     for (int32_t idx = 0; idx < n; ++idx) {
       const int32_t v = order[(size_t)idx];
       const int32_t old = comm[(size_t)v];
-      touched.clear();
-      for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) {
-        const int32_t c = comm[(size_t)g.adj[(size_t)q]];
-        if (!seen[(size_t)c]) { seen[(size_t)c] = 1; touched.push_back(c); }
-        wto[(size_t)c] += g.w[(size_t)q];
+      const Scan *sn = nullptr;
+      if (nhelp > 0) {
+        uint8_t expect = 0;
+        if (!state[(size_t)idx].compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) {
+          while (state[(size_t)idx].load(std::memory_order_acquire) != 2) std::this_thread::yield();    // a helper is finishing it
+          const Scan &slot = ring[(size_t)(idx % WINDOW)];
+          if (use_scans && stamp[(size_t)v] <= slot.epoch) { sn = &slot; ++used; ++used_blk; }
+          else { ++stale; ++stale_blk; }
+        }
       }
+      if (!sn) { scan_vertex(g, comm_p, v, my_sc, my_scan); sn = &my_scan; }
+      double w_old = 0.0;
+      for (size_t t = 0; t < sn->cid.size(); ++t)
+        if (sn->cid[t] == old) { w_old = sn->cw[t]; break; }
       tot[(size_t)old] -= k[(size_t)v];                         // take v out of its community
       const double kv = k[(size_t)v];
       int32_t best = old;
-      double best_gain = wto[(size_t)old] - resolution * tot[(size_t)old] * kv / m2;   // staying put
-      for (int32_t c : touched) {
+      double w_best = w_old;
+      double best_gain = w_old - resolution * tot[(size_t)old] * kv / m2;   // staying put
+      for (size_t t = 0; t < sn->cid.size(); ++t) {
+        const int32_t c = sn->cid[t];
         if (c == old) continue;
-        const double gain = wto[(size_t)c] - resolution * tot[(size_t)c] * kv / m2;
-        if (gain > best_gain) { best_gain = gain; best = c; }
+        const double gain = sn->cw[t] - resolution * tot[(size_t)c] * kv / m2;
+        if (gain > best_gain) { best_gain = gain; best = c; w_best = sn->cw[t]; }
       }
       tot[(size_t)best] += kv;
-      comm[(size_t)v] = best;
       if (best != old) {
         ++changed;
         const double lv = 2.0 * g.loop[(size_t)v];
-        in[(size_t)old] -= 2.0 * wto[(size_t)old] + lv;
-        in[(size_t)best] += 2.0 * wto[(size_t)best] + lv;
+        in[(size_t)old] -= 2.0 * w_old + lv;
+        in[(size_t)best] += 2.0 * w_best + lv;
+        __atomic_store_n(&comm_p[(size_t)v], best, __ATOMIC_RELAXED);
+        const uint64_t e = epoch.load(std::memory_order_relaxed) + 1;
+        if (use_scans)                                          // scans of v's neighbours that started before this move are stale
+          for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) stamp[(size_t)g.adj[(size_t)q]] = e;
+        epoch.store(e, std::memory_order_release);
       }
-      for (int32_t c : touched) { wto[(size_t)c] = 0.0; seen[(size_t)c] = 0; }
+      if (nhelp > 0) {
+        decided.store(idx + 1, std::memory_order_release);
+        if (use_scans && (idx & 1023) == 1023) {                   // every 1024 positions: how many scans were stale?
+          const int32_t w = window.load(std::memory_order_relaxed);
+          if (2 * stale_blk > used_blk + stale_blk) {              // most: stay closer behind the decider, or -- already close (the
+            if (w > WINDOW_MIN) window.store(std::max(WINDOW_MIN, w / 4), std::memory_order_relaxed);   // first pass: everything
+            else { phase.store(0, std::memory_order_release); use_scans = false; }   // moves) -- park the helpers and stop stamping
+          } else if (10 * stale_blk < used_blk + stale_blk && w < WINDOW) window.store(w * 2, std::memory_order_relaxed);
+          used_blk = stale_blk = 0;
+        }
+      }
     }
-    if (getenv("DYNAALIGN_LOUVAIN_DEBUG")) fprintf(stderr, "[louvain] n=%d pass: %lld moved\n", n, (long long)changed);
+    if (nhelp > 0) phase.store(0, std::memory_order_release);
+    if (debug)
+      fprintf(stderr, "[louvain] n=%d pass: %lld moved, %.3f s (%d helper threads: %lld scans used, %lld stale)\n", n, (long long)changed,
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count(), nhelp, (long long)used, (long long)stale);
+    if (debug && nhelp > 0) fprintf(stderr, "   helper scans so far %llu, avg %.2f us\n", (unsigned long long)dbg_cnt.load(), dbg_cnt.load() ? dbg_ns.load() / 1e3 / dbg_cnt.load() : 0.0);
     if (changed == 0) break;
     *moved = true;
     const double q_now = modularity_now();
     if (!(q_now > q_prev)) break;                               // igraph: keep passing only while modularity improves
     q_prev = q_now;
   }
+  phase.store(2, std::memory_order_release);
+  for (auto &h : helpers) h.join();
   // renumber in order of first appearance by vertex
   std::vector<int32_t> newid((size_t)n, -1);
   int32_t nc = 0;
@@ -278,30 +435,46 @@ void aggregate(const Graph &g, const std::vector<int32_t> &comm, int32_t nc, Gra
     std::vector<int64_t> f(mptr.begin(), mptr.end() - 1);
     for (int32_t v = 0; v < g.n; ++v) members[(size_t)f[(size_t)comm[(size_t)v]]++] = v;
   }
-  std::vector<double> acc((size_t)nc, 0.0);
-  std::vector<char> seen((size_t)nc, 0);
-  std::vector<int32_t> touched;
-  for (int32_t c = 0; c < nc; ++c) {
-    touched.clear();
-    double inner = 0.0;                                        // sum over ordered pairs inside c (each edge twice)
-    for (int64_t t = mptr[(size_t)c]; t < mptr[(size_t)c + 1]; ++t) {
-      const int32_t v = members[(size_t)t];
-      out.loop[(size_t)c] += g.loop[(size_t)v];
-      for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) {
-        const int32_t d = comm[(size_t)g.adj[(size_t)q]];
-        if (d == c) { inner += g.w[(size_t)q]; continue; }
-        if (!seen[(size_t)d]) { seen[(size_t)d] = 1; touched.push_back(d); }
-        acc[(size_t)d] += g.w[(size_t)q];
+  // one community at a time, handed out by an atomic counter to a few threads (each community's sums run over its members in
+  // ascending vertex order and their canonical adjacency, whoever computes them); the lists are concatenated in community order
+  std::vector<std::vector<int32_t>> cadj((size_t)nc);
+  std::vector<std::vector<double>> cwt((size_t)nc);
+  const int nthreads = host_threads((int64_t)g.adj.size());
+  std::atomic<int32_t> next_c(0);
+  run_threads(nthreads, [&](int) {
+    std::vector<double> acc((size_t)nc, 0.0);
+    std::vector<char> seen((size_t)nc, 0);
+    std::vector<int32_t> touched;
+    for (;;) {
+      const int32_t c = next_c.fetch_add(1, std::memory_order_relaxed);
+      if (c >= nc) break;
+      touched.clear();
+      double inner = 0.0, loops = 0.0;                         // inner: sum over ordered pairs inside c (each edge twice)
+      for (int64_t t = mptr[(size_t)c]; t < mptr[(size_t)c + 1]; ++t) {
+        const int32_t v = members[(size_t)t];
+        loops += g.loop[(size_t)v];
+        for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) {
+          const int32_t d = comm[(size_t)g.adj[(size_t)q]];
+          if (d == c) { inner += g.w[(size_t)q]; continue; }
+          if (!seen[(size_t)d]) { seen[(size_t)d] = 1; touched.push_back(d); }
+          acc[(size_t)d] += g.w[(size_t)q];
+        }
+      }
+      out.loop[(size_t)c] = loops + 0.5 * inner;               // an undirected edge inside c = a loop of that weight
+      std::sort(touched.begin(), touched.end());
+      cadj[(size_t)c].assign(touched.begin(), touched.end());
+      cwt[(size_t)c].resize(touched.size());
+      for (size_t t = 0; t < touched.size(); ++t) {
+        const int32_t d = touched[t];
+        cwt[(size_t)c][t] = acc[(size_t)d];
+        acc[(size_t)d] = 0.0;
+        seen[(size_t)d] = 0;
       }
     }
-    out.loop[(size_t)c] += 0.5 * inner;                        // an undirected edge inside c = a loop of that weight
-    std::sort(touched.begin(), touched.end());
-    for (int32_t d : touched) {
-      out.adj.push_back(d);
-      out.w.push_back(acc[(size_t)d]);
-      acc[(size_t)d] = 0.0;
-      seen[(size_t)d] = 0;
-    }
+  });
+  for (int32_t c = 0; c < nc; ++c) {
+    out.adj.insert(out.adj.end(), cadj[(size_t)c].begin(), cadj[(size_t)c].end());
+    out.w.insert(out.w.end(), cwt[(size_t)c].begin(), cwt[(size_t)c].end());
     out.ptr[(size_t)c + 1] = (int64_t)out.adj.size();
   }
   out.total = 0.0;

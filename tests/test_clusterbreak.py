@@ -207,3 +207,31 @@ def test_clusterbreak_on_oracle_similarities(da):
     assert all(int(l.split(".")[0]) <= r.calls for l in labels)
     assert [lv["itr"] for lv in r.levels] == list(range(1, r.calls + 1))
     assert r.levels[0]["n"] == n
+
+
+def _planted_graph(rng, n, groups, p_in, p_out, levels=50):
+    """dense-ish planted-partition graph with DISCRETE weights k/levels (MinHash-like: exact ties are common)"""
+    lab = rng.randint(0, groups, n)
+    iu, ju = np.triu_indices(n, 1)
+    keep = rng.random_sample(iu.size) < np.where(lab[iu] == lab[ju], p_in, p_out)
+    ei, ej = iu[keep].astype(np.int32), ju[keep].astype(np.int32)
+    ew = (rng.randint(1, levels + 1, ei.size) / float(levels)).astype(np.float64)
+    return ei, ej, ew
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_louvain_result_does_not_depend_on_the_thread_count(da, monkeypatch, seed):
+    """csrc/louvain.cpp: helper threads scan neighbourhoods ahead of the deciding thread and the CSR build / aggregation are
+    threaded; memberships AND modularity must be bit-identical to the one-thread run whatever the count or the timing"""
+    rng = np.random.RandomState(seed)
+    n = 1500
+    ei, ej, ew = _planted_graph(rng, n, 12, 0.5, 0.04)
+    perm = rng.permutation(ei.size)
+    monkeypatch.setenv("DYNAALIGN_LOUVAIN_THREADS", "1")
+    base, q0 = da.louvain(n, ei, ej, ew, resolution=1.05, seed=seed, return_modularity=True)
+    assert len(np.unique(base)) > 1
+    for threads in ("2", "4", "7"):
+        monkeypatch.setenv("DYNAALIGN_LOUVAIN_THREADS", threads)
+        for rep in range(3):                                    # the helpers' timing differs from run to run
+            m, q = da.louvain(n, ei[perm], ej[perm], ew[perm], resolution=1.05, seed=seed, return_modularity=True)
+            assert np.array_equal(m, base) and q == q0
