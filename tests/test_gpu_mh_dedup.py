@@ -118,3 +118,45 @@ def test_h3n2_like_12000_properties(da):
         del os.environ["DYNAALIGN_MH_NO_DEDUP"]
     assert torch.equal(out.view(torch.int64), direct.view(torch.int64))
     assert torch.equal(out, out.T) and bool((out.diagonal() == 1.0).all())
+
+
+def test_degenerate_unique_tables(da, small_n_route):
+    """U = 1 (every sequence identical), U = 2, and a set whose duplicates all sit at the end / the start"""
+    a, b = "ACDEFGHIKLMNPQRSTVWY", "YWVTSRQPNMLKIHGFEDCA"
+    rng = np.random.RandomState(3)
+    singles = duplicated_set(rng, 1, 0, 300, 18, 24)
+    for seqs in ([a] * 300, [a] * 257 + [b] * 3, [a, b] * 200, singles + [singles[0]] * 120, [singles[5]] * 130 + singles):
+        got, route = run(seqs, 4, 96)
+        assert route["dedup"] and route["unique"] == len(set(seqs))
+        assert same(got, oracle(seqs, 4, 96))
+
+
+@pytest.mark.parametrize("n", [255, 256, 257, 383, 384, 385, 511])
+def test_sizes_around_the_tile_edges(da, small_n_route, n):
+    """n < 256: no interior tile exists, the route is not taken (direct kernels); n = 256 / 384: all tiles full; +-1: border column / row"""
+    rng = np.random.RandomState(n)
+    seqs = duplicated_set(rng, 40, n - 60, 60, 10, 22)
+    got, route = run(seqs, 3, 40)
+    assert route["dedup"] == (n >= 256)
+    assert same(got, oracle(seqs, 3, 40))
+
+
+def test_odd_leading_dimension_and_unaligned_output(da, small_n_route):
+    """the wide-store kernels need an even ld and a 16-byte aligned matrix; anything else takes the scalar kernels -- same values"""
+    import torch
+    from dynaalign_amd import device
+    import dynaalign_amd as da_
+    rng = np.random.RandomState(21)
+    seqs = duplicated_set(rng, 60, 500, 100, 10, 22)
+    n = len(seqs)
+    want = oracle(seqs, 4, 64)
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(res, off)
+    seeds = da_.hash_family_seeds(12345, 64)
+    for ld, shift in ((n + 1, 0), (n + 2, 1), (n, 1)):
+        buf = torch.zeros(n * ld + 8, dtype=torch.float64, device="cuda")
+        out = buf[shift:shift + n * ld].view(n, ld)[:, :n]
+        device.similarity_mh(ds, 4, 64, seeds, out=out)
+        torch.cuda.synchronize()
+        assert device.mh_last_route()["dedup"]
+        assert same(out.cpu().numpy(), want)
