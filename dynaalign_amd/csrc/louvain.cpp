@@ -64,7 +64,7 @@ struct Mt19937 {   // ISO C++ [rand.predef] mt19937, restated (std::shuffle / un
 // Host threads for the data-parallel parts (CSR build, strengths, aggregation) and for the speculative neighbourhood scans of
 // the local-moving passes.  Nothing the function returns depends on the count (DYNAALIGN_LOUVAIN_THREADS overrides it; 1 = serial).
 int host_threads(int64_t work_items) {
-  int t = (int)std::min<int64_t>(16, std::max<int64_t>(1, work_items / 2000000));
+  int t = (int)std::min<int64_t>(16, std::max<int64_t>(1, work_items / 250000));   // (a thread per 250k adjacency entries, at most 16)
   if (const char *e = getenv("DYNAALIGN_LOUVAIN_THREADS")) t = std::max(1, atoi(e));
   const unsigned hw = std::thread::hardware_concurrency();
   if (hw > 0 && (unsigned)t > hw) t = (int)hw;
