@@ -162,11 +162,7 @@ __device__ __forceinline__ uint32_t or_xor(uint32_t d, uint32_t a, uint32_t b) {
 typedef double da_double2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_store2(double *p, double a, double b) {
   da_double2_t v = {a, b};
-#ifdef K2_PLAIN_STORES   // experiment (tools/k2_variants.sh): write-back stores instead of streaming ones
-  *reinterpret_cast<da_double2_t *>(p) = v;
-#else
-  __builtin_nontemporal_store(v, reinterpret_cast<da_double2_t *>(p));
-#endif
+  __builtin_nontemporal_store(v, reinterpret_cast<da_double2_t *>(p));   // (write-back stores wash the planes out of L2: +0.4 ms)
 }
 
 #ifndef K2_RING_DEPTH
@@ -296,13 +292,6 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring; afterwards counters, then the ratio table
   static_assert(sizeof(lds_ab) / (sizeof(double)) == K2_A12_TABLE_MAX, "launch_mh_compare's table guard must match the ring size");
   if (K2_PRO_PRIO) __builtin_amdgcn_s_setprio(K2_PRO_PRIO);
-#ifdef K2_FIRST_STAGGER   // experiment: de-correlate the first generation of workgroups (they all start together and a tile
-  // takes the same time everywhere, so their store phases would hit HBM as one burst, generation after generation)
-  if (blockIdx.x < (unsigned)K2_FIRST_STAGGER) {
-    const unsigned w = ((blockIdx.x * 2654435761u) >> 20) % 21u;
-    for (unsigned q = 0; q < w; ++q) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   K2_STAMP(0);
   K2_STAMP_HW();
   const int64_t bid = blockIdx.x;
@@ -624,9 +613,6 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
   register uint32_t r121 asm("v121") = lds_base + (uint32_t)((K2_TILE * SEGS + tx0 * SEGS) * 16);   // ... first column operand
   register uint32_t r124 asm("v124") = (uint32_t)tid * 4u;
 
-#ifdef K2_STAGGER    // experiment: the CU's resident workgroups start a quarter of a tile period apart
-  for (int w = 0; w < ((slot ^ (slot >> 5)) & 3) * K2_STAGGER; ++w) __builtin_amdgcn_s_sleep(127);
-#endif
   TileId cur, nxt;
 #ifdef K2_DYNAMIC
   __shared__ unsigned int s_next[2];
@@ -1706,8 +1692,7 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   if (n <= 0) return DA_OK;
   if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "expand: matrix too large");
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "expand: bad output kind");
-  const int ft = getenv("DYNAALIGN_EXPAND_TILE") ? atoi(getenv("DYNAALIGN_EXPAND_TILE")) : 64;   // experiment knob: 64 or 128
-  const int TB = (int)ceil_div(n, ft == 128 ? 128 : 64);
+  const int TB = (int)ceil_div(n, 64);
   const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   const int64_t per_xcd = ceil_div(tiles, 8);
@@ -1715,7 +1700,7 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   // float64 with a column-gathered table from the caller: interior off-diagonal 128 x 128 tiles by the two streaming passes,
   // the rest (diagonal, borders) by the 64 x 64 kernel below
   const bool fast = d_F != nullptr && expand_rows_workspace_bytes(n, U, kind, is_nw, n_hash, nw_max_len) != 0 && (ld & 1) == 0 &&
-                    (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && ft == 64;
+                    (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
   if (fast) {
     const int64_t ld_f = ceil_div(n, 8) * 8;
     const size_t row_bytes = (size_t)ld_d * 2;
@@ -1752,13 +1737,8 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   const int skip_fast = fast ? 1 : 0;
   if (fast) grid.x = leftover_blocks64(n);   // the 64 x 64 kernel then only visits the diagonal 128-tiles and the border column
 #define DA_EXP(F, W, T) hipLaunchKernelGGL((k_expand_unique<F, W, T>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd, skip_fast)
-  if (ft == 128) {
-    if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 128); else DA_EXP(true, false, 128); }
-    else { if (is_nw) DA_EXP(false, true, 128); else DA_EXP(false, false, 128); }
-  } else {
-    if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 64); else DA_EXP(true, false, 64); }
-    else { if (is_nw) DA_EXP(false, true, 64); else DA_EXP(false, false, 64); }
-  }
+  if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 64); else DA_EXP(true, false, 64); }
+  else { if (is_nw) DA_EXP(false, true, 64); else DA_EXP(false, false, 64); }
 #undef DA_EXP
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
