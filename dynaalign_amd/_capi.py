@@ -47,6 +47,12 @@ SIGNATURES = {
     "da_nw_last_route": (_i32, [_vp, _vp, _vp, _vp]),
     "da_dev_similarity_mh": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "da_mh_last_route": (_i32, [_vp, _vp, _vp, _vp, _vp]),
+    "da_dev_unique_plan_bytes": (_sz, [_i64, _i64]),
+    "da_dev_unique_plan": (_i32, [_vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp]),
+    "da_dev_shards_to_table": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "da_dev_nw_unique_rows": (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
+    "da_dev_expand_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
+    "da_dev_expand_unique": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp, _i64, _vp]),
     "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "da_similarity_mh_edges": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, C.c_double, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -76,6 +82,13 @@ SIGNATURES = {
 
 DA_EXCHANGE = {"rows": 0, "allgather": 1, "peercopy": 2}
 DA_PHASES = ("setup", "compute", "exchange", "finalize", "d2h", "total")
+
+
+class DaUniquePlan(C.Structure):
+    """struct da_unique_plan (include/dynaalign.h): device pointers into the plan's workspace"""
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_int32), ("n", C.c_int64), ("unique", C.c_int64),
+                ("d_uidx", C.c_void_p), ("d_ufirst", C.c_void_p), ("d_ulast", C.c_void_p), ("d_ubytes", C.c_void_p),
+                ("d_uoffsets", C.c_void_p), ("d_minfirst", C.c_void_p), ("d_maxlast", C.c_void_p)]
 
 
 class DaOpts(C.Structure):

@@ -623,6 +623,88 @@ int da_mh_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, 
   return DA_OK;
 }
 
+// ---- pieces of the duplicate-collapsing routes for callers that orchestrate the steps themselves (the one-process-per-GPU
+// sharded drivers in dynaalign_amd/sharding.py: every rank builds the same plan, computes ITS shard of the unique table,
+// all-gathers the shards -- 0.2x the bytes of the N x N shards at N = 100k -- and expands locally)
+size_t da_dev_unique_plan_bytes(int64_t n, int64_t total_bytes) {
+  if (n <= 0) return 256;
+  return nw_dedup_workspace_bytes(n, total_bytes > 0 ? total_bytes : 1);
+}
+
+int da_dev_unique_plan(const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n, int64_t total_bytes, void *d_work, size_t work_bytes,
+                       da_unique_plan *plan, void *stream_v) {
+  if (!plan || plan->struct_size < sizeof(da_unique_plan)) return fail(DA_ERR_BAD_ARG, "da_unique_plan: NULL or struct_size too small");
+  if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
+  if (n > 0x7ffffff0LL) return fail(DA_ERR_UNSUPPORTED, "unique plan: n too large");
+  if (!d_bytes || !d_offsets || !d_work) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if ((reinterpret_cast<uintptr_t>(d_work) & 255) || work_bytes < da_dev_unique_plan_bytes(n, total_bytes))
+    return fail(DA_ERR_BAD_ARG, "workspace must be 256-byte aligned and hold da_dev_unique_plan_bytes(n, total_bytes) bytes");
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  int rc;
+  const NwDedupPlan p = nw_dedup_layout(d_work, n, total_bytes > 0 ? total_bytes : 1);
+  if ((rc = launch_nw_dedup_count(d_bytes, d_offsets, n, p, stream)) != DA_OK) return rc;
+  int32_t M = 0, S = 0;
+  DA_HIP_TRY(hipMemcpyAsync(&M, p.pm + n, 4, hipMemcpyDeviceToHost, stream));
+  DA_HIP_TRY(hipMemcpyAsync(&S, p.ps + n, 4, hipMemcpyDeviceToHost, stream));
+  DA_HIP_TRY(hipStreamSynchronize(stream));
+  const int64_t U = (int64_t)M + S;
+  if (U <= 0 || U > n) return fail(DA_ERR_HIP, "unique plan: inconsistent counts (%lld unique of %lld)", (long long)U, (long long)n);
+  if ((rc = launch_nw_dedup_build(d_bytes, d_offsets, n, U, p, stream)) != DA_OK) return rc;
+  plan->n = n; plan->unique = U;
+  plan->d_uidx = p.uidx; plan->d_ufirst = p.ufirst; plan->d_ulast = p.ulast;
+  plan->d_ubytes = p.ucodes; plan->d_uoffsets = p.uoff;
+  plan->d_minfirst = p.minfirst; plan->d_maxlast = p.maxlast;
+  return DA_OK;
+}
+
+int da_dev_shards_to_table(const void *d_gathered, int64_t ld_g, int64_t n, int world, int value_bits, uint16_t *d_table, int64_t ld_table,
+                           void *stream) {
+  if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
+  if (!d_gathered || !d_table) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if (world < 1 || ld_table < n) return fail(DA_ERR_BAD_ARG, "bad world / leading dimension");
+  if (value_bits != 0 && (value_bits < 1 || value_bits > 16)) return fail(DA_ERR_BAD_ARG, "value_bits must be 0 (uint16 blocks) or 1..16");
+  const ShardGeom g = shard_geom(n, world, 128);
+  if (value_bits == 0 && ld_g < g.W) return fail(DA_ERR_BAD_ARG, "ld_g (%lld) < da_shard_ld (%lld)", (long long)ld_g, (long long)g.W);
+  return launch_shards_to_table(d_gathered, ld_g, g, value_bits, d_table, ld_table, static_cast<hipStream_t>(stream));
+}
+
+size_t da_dev_expand_workspace_bytes(int64_t n, int64_t unique, int is_nw, int n_hash, int nw_max_len) {
+  const size_t b = expand_rows_workspace_bytes(n, unique, DA_OUT_F64, is_nw != 0, n_hash, nw_max_len);
+  return b ? b : 256;                                          // (shapes the two streaming passes do not cover use no workspace)
+}
+
+int da_dev_expand_unique(const uint16_t *d_table, int64_t ld_table, int table_world, const da_unique_plan *plan, int is_nw, int n_hash,
+                         int nw_max_len, void *d_work, size_t work_bytes, double *d_out, int64_t ld, void *stream) {
+  if (!plan || plan->struct_size < sizeof(da_unique_plan) || !plan->d_uidx || !plan->d_ufirst) return fail(DA_ERR_BAD_ARG, "bad da_unique_plan");
+  if (!d_table || !d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  const int64_t n = plan->n, U = plan->unique;
+  if (n <= 0 || U <= 0 || U > n || ld < n || ld_table < U) return fail(DA_ERR_BAD_ARG, "bad sizes / leading dimensions");
+  if (!is_nw && (n_hash <= 0 || n_hash > 65535)) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
+  if (table_world < 1) return fail(DA_ERR_BAD_ARG, "table_world must be >= 1");
+  const int64_t rows_local = table_world > 1 ? ceil_div(ceil_div(U, 128), table_world) * 128 : 0;
+  const size_t need = expand_rows_workspace_bytes(n, U, DA_OUT_F64, is_nw != 0, n_hash, nw_max_len);
+  uint16_t *d_F = (need && d_work && work_bytes >= need && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0) ? static_cast<uint16_t *>(d_work) : nullptr;
+  if ((ld_table & 7) || (reinterpret_cast<uintptr_t>(d_table) & 15)) d_F = nullptr;     // the column gather reads the table in 16-byte units
+  return launch_expand_unique(d_table, ld_table, plan->d_uidx, n, DA_OUT_F64, is_nw != 0, n_hash, d_out, ld, static_cast<hipStream_t>(stream),
+                              nw_max_len, d_F, plan->d_ufirst, U, nullptr, nullptr, table_world, rows_local);
+}
+
+int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int64_t row_begin,
+                          int64_t row_end, uint16_t *d_out, int64_t ld, void *stream) {
+  if (!plan || plan->struct_size < sizeof(da_unique_plan) || !plan->d_ubytes || !plan->d_uoffsets || !plan->d_ufirst || !plan->d_minfirst ||
+      !plan->d_maxlast)
+    return fail(DA_ERR_BAD_ARG, "bad da_unique_plan");
+  if (!d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  const int64_t U = plan->unique;
+  if (row_begin < 0 || row_end > U || row_begin > row_end || ld < U) return fail(DA_ERR_BAD_ARG, "bad row range / leading dimension");
+  if (matrix_id < 0 || matrix_id >= matrix_count_host()) return fail(DA_ERR_BAD_MATRIX, "%s", da_status_message(DA_ERR_BAD_MATRIX));
+  if (max_len < 1 || max_len > 64 || gap_open < 0 || gap_ext < 0)
+    return fail(DA_ERR_UNSUPPORTED, "the ordered unique-table sweep serves sequences of 1..64 residues and penalties >= 0");
+  if (row_begin == row_end) return DA_OK;
+  return launch_nw(plan->d_ubytes, plan->d_uoffsets, U, max_len, matrix_id, gap_open, gap_ext, row_begin, row_end, false, DA_OUT_COMPACT, d_out, ld,
+                   nullptr, 0, static_cast<hipStream_t>(stream), 0, 0, plan->d_ufirst, plan->d_minfirst, plan->d_maxlast);
+}
+
 int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues, uint8_t *d_codes,
                      int32_t *d_bad, void *stream) {
   if (total_residues > 0 && (!d_residues || !d_codes || !d_bad)) return fail(DA_ERR_BAD_ARG, "NULL device pointer");

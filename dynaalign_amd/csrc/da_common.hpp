@@ -129,6 +129,8 @@ int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,
                             double *d_out, int64_t ld, hipStream_t stream);   // interior tiles: k_finalize_rows (16-byte stores)
 int64_t shard_packed_bytes(const ShardGeom &g, int value_bits);
+int launch_shards_to_table(const void *d_g, int64_t ld_g, const ShardGeom &geom, int value_bits, uint16_t *d_table, int64_t ld,
+                           hipStream_t stream);
 int launch_pack_shard(const uint16_t *d_local, int64_t ld, const ShardGeom &geom, int value_bits, uint8_t *d_packed,
                       hipStream_t stream);
 int launch_finalize_packed(const uint8_t *d_g, const ShardGeom &geom, int value_bits, int n_hash, double *d_out, int64_t ld,
@@ -155,7 +157,8 @@ int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t 
 // minhash_kernels.hip: out[i][j] = value(D[uidx[min(i,j)]][uidx[max(i,j)]]) for the dense symmetric n x n result
 int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
                          void *d_out, int64_t ld, hipStream_t stream, int nw_max_len = 0, uint16_t *d_F = nullptr,
-                         const int32_t *d_ufirst = nullptr, int64_t U = 0, hipEvent_t after_gather = nullptr, hipEvent_t after_rows = nullptr);
+                         const int32_t *d_ufirst = nullptr, int64_t U = 0, hipEvent_t after_gather = nullptr, hipEvent_t after_rows = nullptr,
+                         int table_world = 1, int64_t table_rows_local = 0);   // table_world > 1: d_D is all-gathered row blocks of cyclic 128-row units
 // bytes of the column-gathered table (d_F) that switches launch_expand_unique to its two streaming passes; 0 = shape not covered
 size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, int n_hash, int nw_max_len);
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,

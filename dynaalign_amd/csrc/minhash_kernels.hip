@@ -1369,6 +1369,15 @@ __device__ __forceinline__ void store_tile_f64(const uint16_t (&t)[FT][FT + 2], 
   }
 }
 
+// Where row r of the unique table lives.  One GPU: row r.  The sharded NW route all-gathers row blocks of cyclic 128-row units
+// (rank p computed units p, p + world, ...; every block holds rows_local rows), so row r sits in block (r / 128) % world.
+struct TableRows { int world; int64_t rows_local; };
+__device__ __forceinline__ int64_t table_row(int r, const TableRows &tr) {
+  if (tr.world <= 1) return r;
+  const int t = r >> 7;
+  return (int64_t)(t % tr.world) * tr.rows_local + (int64_t)(t / tr.world) * 128 + (r & 127);
+}
+
 // 64 x 64 tile of block b when the interior 128-tiles were taken by a 128 x 128 kernel: quarter (b & 3) of 128-tile b >> 2, the
 // T128 diagonal tiles first, then the last tile column when n is not a multiple of 128 (grid: leftover_blocks64)
 __device__ __forceinline__ TileId leftover_tile64(unsigned b, int n, int TB) {
@@ -1500,10 +1509,29 @@ static bool finalize_rows_ok(const ShardGeom &geom, const void *d_g, int64_t ld_
 // row pieces: 26.7 ms; persistent workgroups: 23.6 ms).  64 divides the shard tile (128 / 64), so which rank's block and
 // which folded row a tile reads from is workgroup-uniform integer arithmetic.  MH widens through
 // an LDS table built with the reference's divide.
-template <bool IS_NW>
+// uint16 tile as it is (the sharded duplicate route rebuilds the symmetric table of the unique strings from the gathered shards)
+template <int FT>
+__device__ __forceinline__ void store_tile_u16(const uint16_t (&t)[FT][FT + 2], uint16_t *__restrict__ out, int64_t ld, int n, int i0, int j0) {
+  constexpr int RS = 256 / FT;
+  const int tx = threadIdx.x & (FT - 1), ty = threadIdx.x / FT;
+  const int j = j0 + tx;
+  uint16_t *o = out + (int64_t)i0 * ld + j;
+  for (int r = ty; r < FT; r += RS) {
+    const int i = i0 + r;
+    if (i < n && j < n && j >= i) o[(int64_t)r * ld] = t[r][tx];
+  }
+  const int im = i0 + tx;
+  uint16_t *om = out + (int64_t)j0 * ld + im;
+  for (int r = ty; r < FT; r += RS) {
+    const int jm = j0 + r;
+    if (im < n && jm < n && jm > im) om[(int64_t)r * ld] = t[tx][r];
+  }
+}
+template <bool IS_NW, bool U16 = false>
 __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__restrict__ G, int64_t ld_g, ShardGeom geom,
-                                                          int n_hash, double *__restrict__ out, int64_t ld, int TB,
+                                                          int n_hash, void *__restrict__ out_v, int64_t ld, int TB,
                                                           int64_t ntiles, int64_t per_xcd, int skip_fast) {
+  double *out = static_cast<double *>(out_v);
   constexpr int FT = 64, TABLE = 2048;
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ double ratio[IS_NW ? 1 : TABLE];
@@ -1535,7 +1563,8 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
     if (i < n && j < n && j >= i) t[r][tx] = src[(int64_t)r * ld_g];
   }
   __syncthreads();
-  store_tile_f64<64>(t, widen, out, ld, n, i0, j0);
+  if (U16) store_tile_u16<64>(t, static_cast<uint16_t *>(out_v), ld, n, i0, j0);
+  else store_tile_f64<64>(t, widen, out, ld, n, i0, j0);
 }
 
 // Dense symmetric n x n result from the square table D of UNIQUE sequences (NW dedupe, nw_kernels.hip):
@@ -1546,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_finalize_sharded(const uint16_t *__rest
 template <bool F64, bool IS_NW, int FT>
 __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                        int n, int n_hash, void *__restrict__ out_v, int64_t ld, int TB,
-                                                       int64_t ntiles, int64_t per_xcd, int skip_fast) {
+                                                       int64_t ntiles, int64_t per_xcd, int skip_fast, TableRows trows) {
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ int32_t ur[FT], uc[FT];
   const TileId tt = skip_fast ? leftover_tile64(blockIdx.x, n, TB) : decode_tile_xcd(blockIdx.x, per_xcd, ntiles, TB);
@@ -1569,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_expand_unique(const uint16_t *__restric
   const int32_t cj = uc[tx];
   for (int r = ty; r < FT; r += RS) {
     const int i = i0 + r;
-    if (i < n && j < n && j >= i) t[r][tx] = D[(int64_t)ur[r] * ld_d + cj];
+    if (i < n && j < n && j >= i) t[r][tx] = D[table_row(ur[r], trows) * ld_d + cj];
   }
   __syncthreads();
   if (F64) {
@@ -1604,13 +1633,13 @@ constexpr int GC_THREADS = 1024;
 // registers while the current one is gathered out of LDS (U <= 65536 -> at most 8 16-byte units per thread)
 __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                                const int32_t *__restrict__ ufirst, int n, int U, uint16_t *__restrict__ F,
-                                                               int64_t ld_f) {
+                                                               int64_t ld_f, TableRows trows) {
   extern __shared__ __attribute__((aligned(16))) uint16_t gc_row[];   // ld_d entries
   const int units = (int)(ld_d >> 3);
   uint4 pre[8];
 #define GC_FETCH(row)                                                                                   \
   {                                                                                                     \
-    const uint4 *src_ = reinterpret_cast<const uint4 *>(D + (int64_t)(row) * ld_d);                     \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(D + table_row((row), trows) * ld_d);            \
     _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                     \
       const int u = (int)threadIdx.x + q * GC_THREADS;                                                  \
       pre[q] = u < units ? src_[u] : make_uint4(0, 0, 0, 0);                                            \
@@ -1688,7 +1717,8 @@ size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, i
 
 int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
                          void *d_out, int64_t ld, hipStream_t stream, int nw_max_len, uint16_t *d_F, const int32_t *d_ufirst, int64_t U,
-                         hipEvent_t after_gather, hipEvent_t after_rows) {
+                         hipEvent_t after_gather, hipEvent_t after_rows, int table_world, int64_t table_rows_local) {
+  const TableRows trows{table_world, table_rows_local};
   if (n <= 0) return DA_OK;
   if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "expand: matrix too large");
   if (kind != DA_OUT_F64 && kind != DA_OUT_COMPACT) return fail(DA_ERR_BAD_ARG, "expand: bad output kind");
@@ -1720,7 +1750,7 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
     const int gc_wg = row_bytes <= 40 * 1024 ? 2 : 1;                  // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
     const int64_t gc_grid = std::min<int64_t>(U, (int64_t)gc_cus.load() * gc_wg);
     hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)gc_grid), dim3(GC_THREADS), row_bytes, stream, d_D, ld_d, d_uidx, d_ufirst, (int)n,
-                       (int)U, d_F, ld_f);
+                       (int)U, d_F, ld_f, trows);
     if (after_gather) DA_HIP_TRY(hipEventRecord(after_gather, stream));
     const int T128 = (int)ceil_div(n, 128);
     const int64_t t128 = (int64_t)T128 * (T128 + 1) / 2, px = ceil_div(t128, 8);
@@ -1736,7 +1766,7 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   if (after_rows) DA_HIP_TRY(hipEventRecord(after_rows, stream));
   const int skip_fast = fast ? 1 : 0;
   if (fast) grid.x = leftover_blocks64(n);   // the 64 x 64 kernel then only visits the diagonal 128-tiles and the border column
-#define DA_EXP(F, W, T) hipLaunchKernelGGL((k_expand_unique<F, W, T>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd, skip_fast)
+#define DA_EXP(F, W, T) hipLaunchKernelGGL((k_expand_unique<F, W, T>), grid, dim3(256), 0, stream, d_D, ld_d, d_uidx, (int)n, n_hash, d_out, ld, TB, tiles, per_xcd, skip_fast, trows)
   if (kind == DA_OUT_F64) { if (is_nw) DA_EXP(true, true, 64); else DA_EXP(true, false, 64); }
   else { if (is_nw) DA_EXP(false, true, 64); else DA_EXP(false, false, 64); }
 #undef DA_EXP
@@ -1807,9 +1837,11 @@ __global__ __launch_bounds__(256) void k_pack_shard(const uint16_t *__restrict__
 }
 
 // k_finalize_sharded reading packed blocks (MH only): G = world blocks of block_bytes each
+template <bool U16 = false>
 __global__ __launch_bounds__(256) void k_finalize_packed(const uint8_t *__restrict__ G, int64_t block_bytes, ShardGeom geom,
-                                                         int nhi, int n_hash, double *__restrict__ out, int64_t ld, int TB,
+                                                         int nhi, int n_hash, void *__restrict__ out_v, int64_t ld, int TB,
                                                          int64_t ntiles, int64_t per_xcd, int skip_fast) {
+  double *out = static_cast<double *>(out_v);
   constexpr int FT = 64, TABLE = 2048;
   __shared__ uint16_t t[FT][FT + 2];
   __shared__ double ratio[TABLE];
@@ -1843,7 +1875,8 @@ __global__ __launch_bounds__(256) void k_finalize_packed(const uint8_t *__restri
     }
   }
   __syncthreads();
-  store_tile_f64<64>(t, widen, out, ld, n, i0, j0);
+  if (U16) store_tile_u16<64>(t, static_cast<uint16_t *>(out_v), ld, n, i0, j0);
+  else store_tile_f64<64>(t, widen, out, ld, n, i0, j0);
 }
 
 int64_t shard_packed_bytes(const ShardGeom &g, int value_bits) {
@@ -1881,8 +1914,29 @@ int launch_finalize_packed(const uint8_t *d_g, const ShardGeom &geom, int value_
                        shard_packed_bytes(geom, value_bits), geom, nhi, n_hash, entries, d_out, ld, T128, t128, px);
     blocks = leftover_blocks64(geom.n);
   }
-  hipLaunchKernelGGL(k_finalize_packed, dim3(blocks), dim3(256), 0, stream, d_g, shard_packed_bytes(geom, value_bits),
+  hipLaunchKernelGGL(k_finalize_packed<false>, dim3(blocks), dim3(256), 0, stream, d_g, shard_packed_bytes(geom, value_bits),
                      geom, nhi, n_hash, d_out, ld, TB, tiles, per_xcd, fast ? 1 : 0);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+// gathered MinHash shards (uint16 folded blocks: value_bits = 0, d_g leading dimension ld_g; packed blocks: value_bits > 0) ->
+// symmetric uint16 count table of geom.n rows (the unique strings of the sharded duplicate route)
+int launch_shards_to_table(const void *d_g, int64_t ld_g, const ShardGeom &geom, int value_bits, uint16_t *d_table, int64_t ld,
+                           hipStream_t stream) {
+  if (geom.n <= 0) return DA_OK;
+  if (geom.n > 0x7fffffffLL || (geom.tile % 64) != 0) return fail(DA_ERR_UNSUPPORTED, "shards -> table: unsupported geometry");
+  const int TB = (int)ceil_div(geom.n, 64);
+  const int64_t tiles = (int64_t)TB * (TB + 1) / 2;
+  if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
+  const int64_t per_xcd = ceil_div(tiles, 8);
+  const dim3 grid((unsigned)(per_xcd * 8));
+  if (value_bits > 0)
+    hipLaunchKernelGGL(k_finalize_packed<true>, grid, dim3(256), 0, stream, static_cast<const uint8_t *>(d_g), shard_packed_bytes(geom, value_bits),
+                       geom, value_bits > 8 ? value_bits - 8 : 0, 1, d_table, ld, TB, tiles, per_xcd, 0);
+  else
+    hipLaunchKernelGGL((k_finalize_sharded<false, true>), grid, dim3(256), 0, stream, static_cast<const uint16_t *>(d_g), ld_g, geom, 1, d_table, ld,
+                       TB, tiles, per_xcd, 0);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

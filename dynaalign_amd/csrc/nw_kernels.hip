@@ -199,7 +199,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   int64_t row_shift = -row_begin;  // local output row = global row + row_shift
   int64_t col_shift = 0;           // local output column = global column + col_shift (direct stores)
   if (ordered) {
-    ti = (int)(L / T);
+    ti = (int)(row_begin / K3_TILE) + (int)(L / T);              // (row_begin, row_end: whole 64-row tile rows of the unique table)
     tj = (int)(L % T);
     if (ti != tj && ord_minfirst[ti] >= ord_maxlast[tj]) return;   // no original pair i < j needs this tile
     allow_mirror = false;
@@ -1066,7 +1066,11 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   const int fold_q = shard_world > 0 ? sg.Q : 0;
   const int64_t fold_w = sg.W;
   int64_t ntiles;
-  if (ord_first) ntiles = (int64_t)T * T;
+  if (ord_first) {
+    if (row_begin % K3_TILE != 0 || (row_end % K3_TILE != 0 && row_end != n))
+      return fail(DA_ERR_BAD_ARG, "ordered NW: the row range must consist of whole 64-row tile rows");
+    ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
+  }
   else if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
   else if (shard_world > 0) ntiles = 2 * (int64_t)sg.Q * T;          // 2 tile rows per 128-row unit, Q units per rank
   else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;

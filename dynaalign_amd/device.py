@@ -231,6 +231,62 @@ def mh_last_route():
             "k2_ms": ms[2], "gather_ms": ms[3], "expand_ms": ms[4], "border_ms": ms[5]}
 
 
+class UniquePlan:
+    """da_dev_unique_plan: byte-identical strings collapsed.  Keeps the workspace tensor the plan's device pointers point into."""
+
+    def __init__(self, bytes_t, offsets_t, n, total):
+        lib = _capi.load()
+        _require_cuda(bytes_t, "sequence bytes")
+        nbytes = int(lib.da_dev_unique_plan_bytes(int(n), int(total)))
+        self.work = torch.empty(nbytes, dtype=torch.uint8, device=bytes_t.device)
+        self.c = _capi.DaUniquePlan()
+        self.c.struct_size = ctypes.sizeof(_capi.DaUniquePlan)
+        _capi.check(lib.da_dev_unique_plan(bytes_t.data_ptr(), offsets_t.data_ptr(), int(n), int(total), self.work.data_ptr(), nbytes,
+                                           ctypes.addressof(self.c), _stream()))
+        self.n, self.unique = int(self.c.n), int(self.c.unique)
+
+    def ptr(self):
+        return ctypes.addressof(self.c)
+
+    def unique_sequences(self, total):
+        """DeviceSequences-like view (residues / offsets / n / total / max_len left to the caller) of the unique strings"""
+        return self.c.d_ubytes, self.c.d_uoffsets
+
+
+def shards_to_table(gathered, ld_g, n, world, value_bits, out=None):
+    """gathered MinHash shards (uint16 blocks: value_bits = 0; packed: their bit count) -> symmetric uint16 table [n][ld]"""
+    ld = -(-int(n) // 8) * 8
+    if out is None:
+        out = torch.empty((int(n), ld), dtype=torch.int16, device=gathered.device)
+    _capi.check(_capi.load().da_dev_shards_to_table(gathered.data_ptr(), int(ld_g), int(n), int(world), int(value_bits), out.data_ptr(),
+                                                    out.stride(0), _stream()))
+    return out
+
+
+def nw_unique_rows(plan, max_len, matrix_name, gap_open, gap_ext, row_begin, row_end, out_rows):
+    """rows [row_begin, row_end) of the ordered unique NW table into out_rows (uint16 view, row row_begin first)"""
+    lib = _capi.load()
+    mid = lib.da_matrix_id(matrix_name.encode("latin-1"))
+    if mid < 0:
+        _capi.check(_capi.DA_ERR_BAD_MATRIX)
+    _capi.check(lib.da_dev_nw_unique_rows(plan.ptr(), int(max_len), mid, int(gap_open), int(gap_ext), int(row_begin), int(row_end),
+                                          out_rows.data_ptr(), out_rows.stride(0), _stream()))
+
+
+def expand_workspace_bytes(n, unique, is_nw, n_hash=0, nw_max_len=0):
+    return int(_capi.load().da_dev_expand_workspace_bytes(int(n), int(unique), 1 if is_nw else 0, int(n_hash), int(nw_max_len)))
+
+
+def expand_unique(table, plan, is_nw, n_hash, nw_max_len, out, table_world=1, work=None):
+    """dense float64 n x n from the table of the unique strings (da_dev_expand_unique)"""
+    if work is None:
+        work = torch.empty(expand_workspace_bytes(plan.n, plan.unique, is_nw, n_hash, nw_max_len), dtype=torch.uint8, device=table.device)
+    _capi.check(_capi.load().da_dev_expand_unique(table.data_ptr(), table.stride(0), int(table_world), plan.ptr(), 1 if is_nw else 0,
+                                                  int(n_hash), int(nw_max_len), work.data_ptr(), work.numel(), out.data_ptr(), out.stride(0),
+                                                  _stream()))
+    return out
+
+
 def nw_last_route():
     """what this thread's last whole-matrix NW call did: dict(n, unique, dedup, plan_ms, dp_ms, expand_ms)"""
     n, u, t = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)

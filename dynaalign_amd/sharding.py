@@ -207,6 +207,108 @@ def nw_sharded_step(plan, work, ds, out, matrix_name="BLOSUM62", gap_open=10, ga
                              lambda g: finalize_shards(plan, g, True, 0, out), group)
 
 
+# ---- the duplicate-collapsing route on the sharded path --------------------------------------------------------------
+# Byte-identical sequences have identical rows and columns of the result (csrc/api.cpp mh_full_symmetric / nw_full_symmetric).
+# Every rank builds the SAME plan from the input it holds anyway (deterministic: no exchange), computes its shard of the table of
+# the U unique strings, the ONE all-gather moves (U/n)^2 of the bytes, and every rank expands the table to the dense n x n
+# matrix with the two streaming passes.  MinHash: the symmetric count table, sharded like the n x n problem (cyclic tile rows,
+# folded upper triangle, 9-bit packed).  NW: the ORDERED square (calc is not symmetric) as row blocks of cyclic 128-row units.
+
+class UniqueSequences:
+    """the plan's unique strings as a DeviceSequences look-alike (tensor views into the plan's workspace)"""
+
+    def __init__(self, uplan, total, max_len):
+        from . import device  # noqa: F401
+        w = uplan.work
+        base = w.data_ptr()
+        bo, oo = uplan.c.d_ubytes - base, uplan.c.d_uoffsets - base
+        self.n = uplan.unique
+        self.total, self.max_len = int(total), int(max_len)
+        self.residues = w[bo:bo + max(self.total, 1)]
+        self.offsets = w[oo:oo + 8 * (self.n + 1)].view(torch.int64)
+        self.codes = self.residues                                    # (NW: the plan was built on the encoded residues)
+
+
+def dedup_worth(n, unique, is_nw, n_hash=0, max_len=0, min_n=2048):
+    """the rule of the single-GPU routes: >= 15 % duplicates and a shape the two expansion passes cover"""
+    from . import device
+    import os
+    min_n = int(os.environ.get("DYNAALIGN_NW_DEDUP_MIN_N" if is_nw else "DYNAALIGN_MH_DEDUP_MIN_N", min_n))
+    if os.environ.get("DYNAALIGN_NW_NO_DEDUP" if is_nw else "DYNAALIGN_MH_NO_DEDUP"):
+        return False
+    if n < min_n or unique * 100 > n * 85:
+        return False
+    if is_nw and not (1 <= max_len <= 64):
+        return False
+    return device.expand_workspace_bytes(n, unique, is_nw, n_hash, max_len) > 256
+
+
+def mh_unique_local(uplan, ds, k, n_hash, d_seeds, rank, world):
+    """K1 + K1b on the unique strings, this rank's packed shard of their count table -> (plan, work)"""
+    from . import device
+    useq = UniqueSequences(uplan, ds.total, ds.max_len)
+    _, planes = device.minhash_signatures(useq, k, n_hash, d_seeds)
+    plan = Plan(uplan.unique, rank, world, MH_TILE)
+    work = PackedWorkspace(plan, n_hash, ds.residues.device)
+    mh_local_block(plan, work, planes, n_hash)
+    pack_local_block(plan, work)
+    return plan, work
+
+
+def mh_unique_finish(uplan, plan, work, gathered, n_hash, out):
+    """gathered packed shards -> symmetric count table of the unique strings -> dense float64 n x n"""
+    from . import device
+    table = device.shards_to_table(gathered, 0, uplan.unique, plan.world, work.bits)
+    return device.expand_unique(table, uplan, False, n_hash, 0, out)
+
+
+def mh_sharded_step_dedup(uplan, ds, k, n_hash, d_seeds, rank, world, out, group=None, marks=None):
+    """similarityMH on `world` ranks with the duplicates collapsed; uplan = device.UniquePlan(ds.residues, ds.offsets, ...).
+    marks: optional list that receives CUDA events after the local shard, the all-gather and the expansion."""
+    plan, work = mh_unique_local(uplan, ds, k, n_hash, d_seeds, rank, world)
+    if marks is not None:
+        marks[0].record()
+    if world > 1:
+        dist.all_gather_into_tensor(work.gathered, work.packed, group=group)
+    else:
+        work.gathered.copy_(work.packed)
+    if marks is not None:
+        marks[1].record()
+    mh_unique_finish(uplan, plan, work, work.gathered, n_hash, out)
+    if marks is not None:
+        marks[2].record()
+    return out
+
+
+def nw_unique_rows_local(uplan, max_len, rank, world, matrix_name="BLOSUM62", gap_open=10, gap_ext=4, device_name="cuda"):
+    """this rank's row block of the ordered unique table: cyclic 128-row units rank, rank + world, ... -> int16 [Q * 128][ld]"""
+    from . import device
+    U = uplan.unique
+    T = -(-U // NW_TILE)
+    Q = -(-T // world)
+    ld = -(-U // 8) * 8
+    local = torch.zeros((Q * NW_TILE, ld), dtype=torch.int16, device=device_name)
+    for q in range(Q):
+        t = q * world + rank
+        if t < T:
+            device.nw_unique_rows(uplan, max_len, matrix_name, gap_open, gap_ext, t * NW_TILE, min((t + 1) * NW_TILE, U),
+                                  local[q * NW_TILE:])
+    return local
+
+
+def nw_sharded_step_dedup(uplan, max_len, rank, world, out, matrix_name="BLOSUM62", gap_open=10, gap_ext=4, group=None):
+    """similarityNW on `world` ranks with the duplicates collapsed; uplan = device.UniquePlan(ds.codes, ds.offsets, ...)
+    (the ENCODED residues)."""
+    from . import device
+    local = nw_unique_rows_local(uplan, max_len, rank, world, matrix_name, gap_open, gap_ext, out.device)
+    if world > 1:
+        gathered = torch.empty((world * local.shape[0], local.shape[1]), dtype=torch.int16, device=out.device)
+        dist.all_gather_into_tensor(gathered.view(torch.uint8), local.view(torch.uint8), group=group)
+    else:
+        gathered = local
+    return device.expand_unique(gathered, uplan, True, 0, max_len, out, table_world=world)
+
+
 # ---- threshold + sparsify on the shards: no N x N exchange at all -----------------------------
 # Every unordered pair (i < j) is computed by exactly one rank (the owner of row i's tile row), so
 #   global histogram = sum of the ranks' histograms      (ONE all-reduce of n_hash + 1 words)

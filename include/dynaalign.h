@@ -219,6 +219,48 @@ int da_dev_similarity_mh(const uint8_t *d_residues, const int64_t *d_offsets, in
                          int k, int n_hash, const uint32_t *d_seeds, double *d_out, int64_t ld, void *stream);
 int da_mh_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, int *plane_bits_out, double *ms6_out);
 
+/* ---- the pieces of the duplicate-collapsing routes, for callers that orchestrate the steps themselves (the one-process-per-GPU
+ * sharded drivers: every rank builds the same plan, computes ITS shard of the unique table with the *_shard / *_unique_rows calls
+ * on the plan's strings, all-gathers the shards -- (U/n)^2 of the bytes -- and expands locally).
+ * da_dev_unique_plan: byte-identical strings of (d_bytes, d_offsets) collapsed (exact: byte-for-byte compares).  Fills *plan with
+ * device pointers INTO d_work (valid while d_work lives): unique id of every input row, first / last occurrence of every unique
+ * string, the unique strings back to back + their offsets, and per 64-row block of the unique table the smallest first / largest
+ * last occurrence (the ordered NW sweep skips what no original pair i < j needs).  Multi-copy strings are numbered before single-copy
+ * ones, each group in input order.  Synchronises `stream` once (the unique count). */
+typedef struct da_unique_plan {
+  uint32_t struct_size;            /* sizeof(da_unique_plan), set by the caller */
+  int32_t reserved;
+  int64_t n, unique;
+  const int32_t *d_uidx;           /* [n] */
+  const int32_t *d_ufirst;         /* [unique] */
+  const int32_t *d_ulast;          /* [unique] */
+  const uint8_t *d_ubytes;         /* the unique strings */
+  const int64_t *d_uoffsets;       /* [unique + 1] */
+  const int32_t *d_minfirst;       /* [ceil(unique / 64)] */
+  const int32_t *d_maxlast;        /* [ceil(unique / 64)] */
+} da_unique_plan;
+size_t da_dev_unique_plan_bytes(int64_t n, int64_t total_bytes);
+int da_dev_unique_plan(const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n, int64_t total_bytes, void *d_work, size_t work_bytes,
+                       da_unique_plan *plan, void *stream);
+/* gathered MinHash shards of an n-row problem (da_dev_mh_compare_shard blocks in rank order: value_bits = 0 and ld_g = da_shard_ld, or
+ * da_dev_pack_shard blocks: value_bits = their bit count) -> the symmetric uint16 count table [n][ld_table]. */
+int da_dev_shards_to_table(const void *d_gathered, int64_t ld_g, int64_t n, int world, int value_bits, uint16_t *d_table, int64_t ld_table,
+                           void *stream);
+/* rows [row_begin, row_end) (whole 64-row tile rows) of the ORDERED unique table of similarityNW, calc(U_p, U_q) with U_p as sequence1
+ * (src/pairwiseSeqAlign.cpp:340-346 evaluates calc(seq[i], seq[j]) for i < j and the function is not symmetric), as uint16
+ * matches<<8|length codes into d_out (row row_begin at d_out[0]); entries no original pair needs stay unwritten.  The plan must have been
+ * built on the ENCODED residues (da_dev_nw_encode).  Sequences of 1..64 residues, penalties >= 0. */
+int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int64_t row_begin,
+                          int64_t row_end, uint16_t *d_out, int64_t ld, void *stream);
+/* dense float64 n x n result from the table of the unique strings: out[i][j] = value(table[u(min(i,j))][u(max(i,j))]), value = count / n_hash
+ * (is_nw = 0) or matches / length (is_nw = 1, nw_max_len = longest sequence).  table_world = 1: row r of the table is row r; > 1: the
+ * table is the all-gathered row blocks of cyclic 128-row units (rank p computed units p, p + world, ...; every block holds
+ * ceil(ceil(unique / 128) / world) * 128 rows).  d_work: da_dev_expand_workspace_bytes bytes (the column-gathered twin of the
+ * table for the two streaming passes; with less, or NULL, the one-kernel expansion runs). */
+size_t da_dev_expand_workspace_bytes(int64_t n, int64_t unique, int is_nw, int n_hash, int nw_max_len);
+int da_dev_expand_unique(const uint16_t *d_table, int64_t ld_table, int table_world, const da_unique_plan *plan, int is_nw, int n_hash,
+                         int nw_max_len, void *d_work, size_t work_bytes, double *d_out, int64_t ld, void *stream);
+
 /* K0: validate + encode residues to BLOSUM row indices 0..23
  * (src/pairwiseSeqAlign.cpp:15-21).  d_codes[total]; *d_bad (int32, caller
  * zeroes it) becomes INT32_MAX - (smallest offending byte position) if any

@@ -218,3 +218,67 @@ def test_nw_edges_sharded_virtual_ranks(da, world, n, lens):
     if world == 1:                                             # the one-call form agrees
         thr, ei, ej, ev, c, vals = sharding.nw_edges_sharded(plans[0], works[0], ds, 0.8)
         assert thr == thr_w and int(c.item()) == len(iw)
+
+
+def _dup_set(n_pool, n_draw, n_single, seed, lo=12, hi=24):
+    rng = np.random.RandomState(seed)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    mk = lambda: "".join(map(chr, alpha[rng.randint(0, 20, rng.randint(lo, hi))]))
+    pool = [mk() for _ in range(n_pool)]
+    seqs = [pool[q] for q in rng.randint(0, n_pool, n_draw)] + [mk() for _ in range(n_single)]
+    rng.shuffle(seqs)
+    return seqs
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("n_draw,n_single", [(500, 140), (900, 380)])
+def test_mh_duplicate_route_virtual_ranks(da, world, n_draw, n_single):
+    """sharded similarityMH with the duplicates collapsed: every rank's packed shard of the UNIQUE strings' count table, their
+    concatenation (= the all-gather), table rebuild + index expansion; bit-identical to the oracle on the full input"""
+    from dynaalign_amd import device, sharding
+    seqs = _dup_set(90, n_draw, n_single, world * 7 + n_draw)
+    n, n_hash = len(seqs), 200
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(res, off)
+    seeds = da.hash_family_seeds(12345, n_hash)
+    d_seeds = torch.from_numpy(seeds.view(np.int32).copy()).cuda()
+    uplan = device.UniquePlan(ds.residues, ds.offsets, ds.n, ds.total)
+    assert uplan.unique == len(set(seqs)) and sharding.dedup_worth(n, uplan.unique, False, n_hash, min_n=1)
+    blocks, last = [], None
+    for r in range(world):
+        plan, work = sharding.mh_unique_local(uplan, ds, 4, n_hash, d_seeds, r, world)
+        blocks.append(work.packed.clone())
+        last = (plan, work)
+    gathered = torch.cat(blocks)
+    out = torch.full((n, n), -1.0, dtype=torch.float64, device="cuda")
+    sharding.mh_unique_finish(uplan, last[0], last[1], gathered, n_hash, out)
+    rc, want = O.similarity_mh(seqs, 4, n_hash, seeds)
+    assert rc == 0 and np.array_equal(out.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    if world == 1:                                             # the step function itself (no collective at world 1)
+        out2 = torch.full((n, n), -1.0, dtype=torch.float64, device="cuda")
+        sharding.mh_sharded_step_dedup(uplan, ds, 4, n_hash, d_seeds, 0, 1, out2)
+        assert torch.equal(out2.view(torch.int64), out.view(torch.int64))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("n_draw,n_single", [(500, 140), (900, 380)])
+def test_nw_duplicate_route_virtual_ranks(da, world, n_draw, n_single):
+    """sharded similarityNW with the duplicates collapsed: row blocks of cyclic 128-row units of the ORDERED unique table, their
+    concatenation, index expansion; the input holds both orders of asymmetric pairs (random order of a small pool)"""
+    from dynaalign_amd import device, sharding
+    seqs = _dup_set(90, n_draw, n_single, world * 11 + n_single) + ["YDYIHIYADKQDRIGWLGNT", "MYCEMNVEIQYMATKNMWNT"] * 3
+    n = len(seqs)
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(res, off)
+    assert int(device.nw_encode(ds).item()) == 0
+    uplan = device.UniquePlan(ds.codes, ds.offsets, ds.n, ds.total)
+    assert uplan.unique == len(set(seqs)) and sharding.dedup_worth(n, uplan.unique, True, 0, ds.max_len, min_n=1)
+    blocks = [sharding.nw_unique_rows_local(uplan, ds.max_len, r, world) for r in range(world)]
+    out = torch.full((n, n), -1.0, dtype=torch.float64, device="cuda")
+    device.expand_unique(torch.cat(blocks, 0), uplan, True, 0, ds.max_len, out, table_world=world)
+    rc, want, _ = O.similarity_nw(seqs)
+    assert rc == 0 and np.array_equal(out.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    if world == 1:
+        out2 = torch.full((n, n), -1.0, dtype=torch.float64, device="cuda")
+        sharding.nw_sharded_step_dedup(uplan, ds.max_len, 0, 1, out2)
+        assert torch.equal(out2.view(torch.int64), out.view(torch.int64))
