@@ -220,10 +220,32 @@ def main():
             return r
         phase_names = ["plan_ms", "codes_ms", "k2_ms", "gather_ms", "expand_ms", "border_ms"]
     else:
+        # every rank builds the same duplicate plan from the input it holds anyway (deterministic: no exchange); when collapsing pays,
+        # the ranks shard the count table of the UNIQUE strings and the one all-gather moves (U/n)^2 of the bytes
+        probe = device.UniquePlan(ds.residues, ds.offsets, n, ds.total)
+        state["dedup"] = sharding.dedup_worth(n, probe.unique, False, n_hash)
+        state["unique"] = probe.unique
+        del probe
         plan = sharding.Plan(n, rank, world, sharding.MH_TILE)
-        work = sharding.PackedWorkspace(plan, n_hash, "cuda")   # counts travel in bits(n_hash) = 9 bits, not 16
+        work = None if state["dedup"] else sharding.PackedWorkspace(plan, n_hash, "cuda")   # counts travel in bits(n_hash) = 9 bits, not 16
 
-        def step(seqs=ds):
+        def step_dedup(seqs=ds):
+            e = [ev() for _ in range(6)]
+            e[0].record()
+            up = device.UniquePlan(seqs.residues, seqs.offsets, seqs.n, seqs.total)
+            e[1].record()
+            uplan_, uwork = sharding.mh_unique_local(up, seqs, k, n_hash, d_seeds, rank, world)   # K1 + K1b + this rank's K2 tiles + pack, unique strings
+            e[2].record()
+            dist.all_gather_into_tensor(uwork.gathered, uwork.packed)
+            e[3].record()
+            table = device.shards_to_table(uwork.gathered, 0, up.unique, world, uwork.bits)
+            e[4].record()
+            device.expand_unique(table, up, False, n_hash, 0, out)
+            e[5].record()
+            state["block_bytes"] = uwork.block_bytes
+            return e
+
+        def step_direct(seqs=ds):
             e = [ev() for _ in range(6)]
             e[0].record()
             pl = signatures_and_planes(e[1], seqs)                # every rank: all signatures (2 MB in)
@@ -235,8 +257,14 @@ def main():
             e[4].record()
             sharding.finalize_shards_packed(plan, work, work.gathered, n_hash, out)
             e[5].record()
+            state["block_bytes"] = work.block_bytes
             return e
-        phase_names = ["k1_signatures", "k1b_codes_to_planes", "k2_compare_shard", "all_gather", "finalize"]
+        if state["dedup"]:
+            step = step_dedup
+            phase_names = ["plan", "codes_and_k2_shard_on_unique", "all_gather", "shards_to_table", "expand"]
+        else:
+            step = step_direct
+            phase_names = ["k1_signatures", "k1b_codes_to_planes", "k2_compare_shard", "all_gather", "finalize"]
 
     def sync():
         if world > 1:
@@ -310,7 +338,10 @@ def main():
                          "peak_lane_ops_per_s": BITOP3_PEAK, "frac": lane_ops / k2 / BITOP3_PEAK}}
 
     k2_key = "k2_ms" if world == 1 else "k2_compare_shard"
-    if world == 1 and route["dedup"]:
+    if world > 1 and state.get("dedup"):
+        main_roof = expand_roofline(phases["expand"])
+        main_roof["note"] += "; here avg_launch_ms is the whole expansion call (column gather + k_expand_rows + border tiles)"
+    elif world == 1 and route["dedup"]:
         # the timed step ran on the table of unique strings: its dominant kernel is the expansion; K2 on U rows rides along
         main_roof = expand_roofline(phases["expand_ms"])
         main_roof["k2_on_unique"] = k2_roofline(phases["k2_ms"], state["bits"], route["unique"], 2)
@@ -327,7 +358,8 @@ def main():
                                % (n, "h3n2-like" if a.workload == "h3n2like" else "uniform"),
                    "n": n, "k": k, "n_hash": n_hash, "pairs": pairs_mh,
                    "sharding": "1 GPU: upper-triangle tiles + mirrored store" if world == 1
-                   else "cyclic tile rows over %d ranks, one RCCL all-gather of the 9-bit packed counts, mirror+widen on every rank" % world},
+                   else "cyclic tile rows (of the unique strings' table when duplicates are collapsed) over %d ranks, one RCCL all-gather of the "
+                        "9-bit packed counts, table rebuild + index expansion / mirror+widen on every rank" % world},
         "roofline": main_roof,
         "phases_ms": phases,
     }
@@ -349,8 +381,11 @@ def main():
             state["bits"] = route["plane_bits"]
     if world > 1:
         line["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                        "all_gather_bytes_per_rank": int(work.block_bytes), "all_gather_ms": phases["all_gather"],
-                        "finalize_ms": phases["finalize"]}
+                        "all_gather_bytes_per_rank": int(state["block_bytes"]), "all_gather_ms": phases["all_gather"],
+                        "finalize_ms": phases["shards_to_table"] + phases["expand"] if state["dedup"] else phases["finalize"]}
+        line["route"] = {"n": n, "unique": state["unique"], "dedup": state["dedup"],
+                         "note": "dedup: every rank builds the same duplicate plan, the ranks shard the count table of the unique strings "
+                                 "(one all-gather of (U/n)^2 of the bytes) and expand it locally; direct: the n x n pair space is sharded"}
 
     # ---- similarityNW on the same set (second half of the metric), >= 3 timed launches
     if not a.no_nw:
@@ -359,9 +394,16 @@ def main():
         if world == 1:
             run_nw = lambda: device.nw(ds, "BLOSUM62", 10, 4, 0, n, True, _capi.DA_OUT_F64, out=out)
         else:
-            nplan = sharding.Plan(n, rank, world, sharding.NW_TILE)
-            nwork = sharding.Workspace(nplan, "cuda")
-            run_nw = lambda: sharding.nw_sharded_step(nplan, nwork, ds, out)
+            nprobe = device.UniquePlan(ds.codes, ds.offsets, n, ds.total)
+            nw_dedup = sharding.dedup_worth(n, nprobe.unique, True, 0, ds.max_len)
+            nw_unique = nprobe.unique
+            del nprobe
+            if nw_dedup:      # ordered table of the unique strings as cyclic row blocks, one all-gather, local expansion
+                run_nw = lambda: sharding.nw_sharded_step_dedup(device.UniquePlan(ds.codes, ds.offsets, n, ds.total), ds.max_len, rank, world, out)
+            else:
+                nplan = sharding.Plan(n, rank, world, sharding.NW_TILE)
+                nwork = sharding.Workspace(nplan, "cuda")
+                run_nw = lambda: sharding.nw_sharded_step(nplan, nwork, ds, out)
         nw_launches = 3
         t_nw, _ = timed_steps(run_nw, nw_launches, 1)
         t_nw /= nw_launches
@@ -369,6 +411,8 @@ def main():
         nw_obj = {"workload": "similarityNW BLOSUM62 go=10 ge=4, same %d 20-mers, dense f64 NxN in HBM" % n,
                   "value": pairs_nw / t_nw, "unit": "pairs/s", "ms": t_nw * 1e3, "launches_timed": nw_launches,
                   "gcups": cells / t_nw / 1e9}
+        if world > 1:
+            nw_obj["route"] = {"n": n, "unique": nw_unique, "dedup": nw_dedup}
         if world == 1:
             # the call collapses byte-identical sequences first (exact): the DP runs on the table of unique strings as an
             # ordered square and the N x N result is an index expansion (da_nw_last_route: unique count + phase times)
@@ -422,8 +466,10 @@ def main():
         else:
             eplan = sharding.Plan(n, rank, world, sharding.MH_TILE)
 
+            ework = work if work is not None else sharding.PackedWorkspace(eplan, n_hash, "cuda")
+
             def run_edges():
-                return sharding.mh_edges_sharded(eplan, work, signatures_and_planes(), n_hash, 0.8)
+                return sharding.mh_edges_sharded(eplan, ework, signatures_and_planes(), n_hash, 0.8)
         run_edges()
         sync()
         t0 = time.perf_counter()
