@@ -229,6 +229,16 @@ class UniqueSequences:
         self.codes = self.residues                                    # (NW: the plan was built on the encoded residues)
 
 
+def unique_table_row(r, world, unique):
+    """host mirror of csrc table_row(): where row r of the unique table sits in the all-gathered row blocks of cyclic 128-row
+    units (rank p computed units p, p + world, ...; every block holds ceil(ceil(unique / 128) / world) * 128 rows)"""
+    if world <= 1:
+        return r
+    rows_local = -(-(-(-unique // NW_TILE)) // world) * NW_TILE
+    t = r // NW_TILE
+    return (t % world) * rows_local + (t // world) * NW_TILE + r % NW_TILE
+
+
 def dedup_worth(n, unique, is_nw, n_hash=0, max_len=0, min_n=2048):
     """the rule of the single-GPU routes: >= 15 % duplicates and a shape the two expansion passes cover"""
     from . import device

@@ -259,3 +259,69 @@ def test_sharded_nw_edges_all_reduce_matches_dense_threshold(built):
     assert {thr for _, thr, _ in results} == {thr_w}
     assert [(a, b) for a, b, _ in got] == list(zip(iw.tolist(), jw.tolist()))
     assert [w for _, _, w in got] == ww.tolist()
+
+
+def _dup_nw_rank_main(rank, world, port, q):
+    """CPU rehearsal of sharding.nw_sharded_step_dedup: the plan's numbering, the cyclic 128-row units of the ORDERED unique table,
+    one all-gather, sharding.unique_table_row + the expansion rule out[i][j] = table[u(min)][u(max)] -- device kernels replaced by
+    the oracle, the collective by gloo"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(5)
+        alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+        mk = lambda: "".join(map(chr, alpha[rng.randint(0, 20, rng.randint(6, 12))]))
+        pool = [mk() for _ in range(40)] + ["YDYIHIYADKQDRIGWLGNT", "MYCEMNVEIQYMATKNMWNT"]
+        seqs = [pool[k] for k in rng.randint(0, len(pool), 160)] + [mk() for _ in range(300)]
+        rng.shuffle(seqs)
+        n = len(seqs)
+        # the plan: multi-copy strings first, then single-copy ones, each group in order of first occurrence (nw_kernels.hip k_dd_assign)
+        first, mult = {}, {}
+        for i, s_ in enumerate(seqs):
+            first.setdefault(s_, i)
+            mult[s_] = mult.get(s_, 0) + 1
+        uniq = sorted(first, key=lambda s_: (mult[s_] == 1, first[s_]))
+        uid = {s_: u for u, s_ in enumerate(uniq)}
+        U = len(uniq)
+        T = -(-U // sharding.NW_TILE)
+        Q = -(-T // world)
+        ld = -(-U // 8) * 8
+        local = np.full((Q * sharding.NW_TILE, ld), 0x7FFF, np.int16)
+        for qq in range(Q):
+            t = qq * world + rank
+            for r in range(t * sharding.NW_TILE, min((t + 1) * sharding.NW_TILE, U)):
+                row = np.zeros(U, np.uint16)
+                for c in range(U):
+                    rc, mt, ln, _, _ = O.nw_pair(uniq[r], uniq[c])               # ORDERED: uniq[r] is sequence1
+                    assert rc == 0
+                    row[c] = (mt << 8) | ln
+                local[qq * sharding.NW_TILE + r % sharding.NW_TILE, :U] = row.view(np.int16)
+        gathered = torch.empty((world * local.shape[0], ld), dtype=torch.int16)
+        dist.all_gather_into_tensor(gathered.view(torch.uint8), torch.from_numpy(local).view(torch.uint8))
+        g = gathered.numpy().view(np.uint16)
+        out = np.empty((n, n), np.float64)
+        for i in range(n):
+            for j in range(i, n):
+                v = int(g[sharding.unique_table_row(uid[seqs[i]], world, U), uid[seqs[j]]])
+                out[i, j] = out[j, i] = (v >> 8) / (v & 255)
+        q.put((rank, out, seqs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_duplicate_route_row_blocks_reassemble_the_oracle_matrix_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dup_nw_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rc, want, _ = O.similarity_nw(results[0][2])
+    assert rc == 0
+    for rank, out, _ in results:
+        assert np.array_equal(out.view(np.uint64), want.view(np.uint64)), rank
