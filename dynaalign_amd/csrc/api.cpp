@@ -689,20 +689,20 @@ int da_dev_expand_unique(const uint16_t *d_table, int64_t ld_table, int table_wo
                               nw_max_len, d_F, plan->d_ufirst, U, nullptr, nullptr, table_world, rows_local);
 }
 
-int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int64_t row_begin,
-                          int64_t row_end, uint16_t *d_out, int64_t ld, void *stream) {
+int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int rank, int world,
+                          uint16_t *d_out, int64_t ld, void *stream) {
   if (!plan || plan->struct_size < sizeof(da_unique_plan) || !plan->d_ubytes || !plan->d_uoffsets || !plan->d_ufirst || !plan->d_minfirst ||
       !plan->d_maxlast)
     return fail(DA_ERR_BAD_ARG, "bad da_unique_plan");
   if (!d_out) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
   const int64_t U = plan->unique;
-  if (row_begin < 0 || row_end > U || row_begin > row_end || ld < U) return fail(DA_ERR_BAD_ARG, "bad row range / leading dimension");
+  if (world < 1 || rank < 0 || rank >= world || ld < U) return fail(DA_ERR_BAD_ARG, "bad rank / world / leading dimension");
   if (matrix_id < 0 || matrix_id >= matrix_count_host()) return fail(DA_ERR_BAD_MATRIX, "%s", da_status_message(DA_ERR_BAD_MATRIX));
   if (max_len < 1 || max_len > 64 || gap_open < 0 || gap_ext < 0)
     return fail(DA_ERR_UNSUPPORTED, "the ordered unique-table sweep serves sequences of 1..64 residues and penalties >= 0");
-  if (row_begin == row_end) return DA_OK;
-  return launch_nw(plan->d_ubytes, plan->d_uoffsets, U, max_len, matrix_id, gap_open, gap_ext, row_begin, row_end, false, DA_OUT_COMPACT, d_out, ld,
-                   nullptr, 0, static_cast<hipStream_t>(stream), 0, 0, plan->d_ufirst, plan->d_minfirst, plan->d_maxlast);
+  // world = 1: the whole table in natural row order; world > 1: this rank's cyclic 128-row units, stored back to back -- one launch
+  return launch_nw(plan->d_ubytes, plan->d_uoffsets, U, max_len, matrix_id, gap_open, gap_ext, 0, U, false, DA_OUT_COMPACT, d_out, ld, nullptr, 0,
+                   static_cast<hipStream_t>(stream), rank, world > 1 ? world : 0, plan->d_ufirst, plan->d_minfirst, plan->d_maxlast);
 }
 
 int da_dev_nw_encode(const uint8_t *d_residues, int64_t total_residues, uint8_t *d_codes,

@@ -201,6 +201,12 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
   if (ordered) {
     ti = (int)(row_begin / K3_TILE) + (int)(L / T);              // (row_begin, row_end: whole 64-row tile rows of the unique table)
     tj = (int)(L % T);
+    if (shard_world > 0) {     // one rank's cyclic 128-row units of the ordered table, stored back to back: local unit u = global unit u * world + rank
+      const int q64 = (int)(L / T), u = q64 >> 1;
+      ti = 2 * (u * shard_world + shard_rank) + (q64 & 1);
+      if (ti >= T) return;
+      row_shift = (int64_t)u * 128 + (int64_t)(q64 & 1) * K3_TILE - (int64_t)ti * K3_TILE;
+    }
     if (ti != tj && ord_minfirst[ti] >= ord_maxlast[tj]) return;   // no original pair i < j needs this tile
     allow_mirror = false;
   } else if (symmetric) {
@@ -1069,7 +1075,8 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   if (ord_first) {
     if (row_begin % K3_TILE != 0 || (row_end % K3_TILE != 0 && row_end != n))
       return fail(DA_ERR_BAD_ARG, "ordered NW: the row range must consist of whole 64-row tile rows");
-    ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
+    if (shard_world > 0) ntiles = 2 * (int64_t)sg.Q * T;            // a rank's Q cyclic units (row_begin = 0, row_end = n)
+    else ntiles = ((row_end - 1) / K3_TILE - row_begin / K3_TILE + 1) * (int64_t)T;
   }
   else if (symmetric) ntiles = (int64_t)T * (T + 1) / 2;
   else if (shard_world > 0) ntiles = 2 * (int64_t)sg.Q * T;          // 2 tile rows per 128-row unit, Q units per rank

@@ -263,13 +263,13 @@ def shards_to_table(gathered, ld_g, n, world, value_bits, out=None):
     return out
 
 
-def nw_unique_rows(plan, max_len, matrix_name, gap_open, gap_ext, row_begin, row_end, out_rows):
-    """rows [row_begin, row_end) of the ordered unique NW table into out_rows (uint16 view, row row_begin first)"""
+def nw_unique_rows(plan, max_len, matrix_name, gap_open, gap_ext, rank, world, out_rows):
+    """rank `rank` of `world`'s cyclic 128-row units of the ordered unique NW table into out_rows (int16 [Q * 128][ld >= unique])"""
     lib = _capi.load()
     mid = lib.da_matrix_id(matrix_name.encode("latin-1"))
     if mid < 0:
         _capi.check(_capi.DA_ERR_BAD_MATRIX)
-    _capi.check(lib.da_dev_nw_unique_rows(plan.ptr(), int(max_len), mid, int(gap_open), int(gap_ext), int(row_begin), int(row_end),
+    _capi.check(lib.da_dev_nw_unique_rows(plan.ptr(), int(max_len), mid, int(gap_open), int(gap_ext), int(rank), int(world),
                                           out_rows.data_ptr(), out_rows.stride(0), _stream()))
 
 

@@ -297,12 +297,8 @@ def nw_unique_rows_local(uplan, max_len, rank, world, matrix_name="BLOSUM62", ga
     T = -(-U // NW_TILE)
     Q = -(-T // world)
     ld = -(-U // 8) * 8
-    local = torch.zeros((Q * NW_TILE, ld), dtype=torch.int16, device=device_name)
-    for q in range(Q):
-        t = q * world + rank
-        if t < T:
-            device.nw_unique_rows(uplan, max_len, matrix_name, gap_open, gap_ext, t * NW_TILE, min((t + 1) * NW_TILE, U),
-                                  local[q * NW_TILE:])
+    local = torch.empty((Q * NW_TILE, ld), dtype=torch.int16, device=device_name)
+    device.nw_unique_rows(uplan, max_len, matrix_name, gap_open, gap_ext, rank, world, local)     # one launch for all of the rank's units
     return local
 
 

@@ -246,12 +246,13 @@ int da_dev_unique_plan(const uint8_t *d_bytes, const int64_t *d_offsets, int64_t
  * da_dev_pack_shard blocks: value_bits = their bit count) -> the symmetric uint16 count table [n][ld_table]. */
 int da_dev_shards_to_table(const void *d_gathered, int64_t ld_g, int64_t n, int world, int value_bits, uint16_t *d_table, int64_t ld_table,
                            void *stream);
-/* rows [row_begin, row_end) (whole 64-row tile rows) of the ORDERED unique table of similarityNW, calc(U_p, U_q) with U_p as sequence1
- * (src/pairwiseSeqAlign.cpp:340-346 evaluates calc(seq[i], seq[j]) for i < j and the function is not symmetric), as uint16
- * matches<<8|length codes into d_out (row row_begin at d_out[0]); entries no original pair needs stay unwritten.  The plan must have been
- * built on the ENCODED residues (da_dev_nw_encode).  Sequences of 1..64 residues, penalties >= 0. */
-int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int64_t row_begin,
-                          int64_t row_end, uint16_t *d_out, int64_t ld, void *stream);
+/* rank `rank` of `world`'s part of the ORDERED unique table of similarityNW, calc(U_p, U_q) with U_p as sequence1
+ * (src/pairwiseSeqAlign.cpp:340-346 evaluates calc(seq[i], seq[j]) for i < j and the function is not symmetric): the cyclic 128-row
+ * units rank, rank + world, ... stored back to back in d_out (ceil(ceil(unique / 128) / world) * 128 rows of ld >= unique uint16
+ * matches<<8|length codes; world = 1: the whole table in natural row order); entries no original pair needs stay unwritten.  The plan
+ * must have been built on the ENCODED residues (da_dev_nw_encode).  Sequences of 1..64 residues, penalties >= 0. */
+int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int rank, int world,
+                          uint16_t *d_out, int64_t ld, void *stream);
 /* dense float64 n x n result from the table of the unique strings: out[i][j] = value(table[u(min(i,j))][u(max(i,j))]), value = count / n_hash
  * (is_nw = 0) or matches / length (is_nw = 1, nw_max_len = longest sequence).  table_world = 1: row r of the table is row r; > 1: the
  * table is the all-gathered row blocks of cyclic 128-row units (rank p computed units p, p + world, ...; every block holds

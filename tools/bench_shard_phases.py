@@ -44,6 +44,35 @@ def main():
         r["nw_w%d" % world] = {"shard_ms_rank0": t_ms(lambda: sharding.nw_local_block(nplan, nwork, ds), 1),
                                "finalize_ms": t_ms(lambda: sharding.finalize_shards(nplan, nwork.gathered, True, 0, out))}
         del nwork
+    # the duplicate route: per-rank pieces with this GPU playing rank 0 (the all-gather itself needs the 8-GPU node)
+    seeds = da.hash_family_seeds(12345, n_hash)
+    d_seeds = torch.from_numpy(seeds.view(np.int32).copy()).cuda()
+    up = device.UniquePlan(ds.residues, ds.offsets, n, ds.total)
+    nup = device.UniquePlan(ds.codes, ds.offsets, n, ds.total)
+    r["unique"] = up.unique
+    r["plan_ms"] = t_ms(lambda: device.UniquePlan(ds.residues, ds.offsets, n, ds.total))
+    for world in (1, 2, 4, 8):
+        state = {}
+        def local():
+            state["pw"] = sharding.mh_unique_local(up, ds, 4, n_hash, d_seeds, 0, world)
+        d = {"codes_and_shard_ms_rank0": t_ms(local)}
+        plan, work = state["pw"]
+        work.gathered.zero_()
+        d["packed_block_GB"] = work.block_bytes / 1e9
+        d["shards_to_table_ms"] = t_ms(lambda: device.shards_to_table(work.gathered, 0, up.unique, world, work.bits))
+        table = device.shards_to_table(work.gathered, 0, up.unique, world, work.bits)
+        ework = torch.empty(device.expand_workspace_bytes(n, up.unique, False, n_hash, 0), dtype=torch.uint8, device="cuda")
+        d["expand_ms"] = t_ms(lambda: device.expand_unique(table, up, False, n_hash, 0, out, work=ework))
+        r["mh_dedup_w%d" % world] = d
+        del work, table, ework, state
+        nd = {"rows_ms_rank0": t_ms(lambda: sharding.nw_unique_rows_local(nup, ds.max_len, 0, world), 1)}
+        blk = sharding.nw_unique_rows_local(nup, ds.max_len, 0, world)
+        nd["block_GB"] = blk.numel() * 2 / 1e9
+        gathered = torch.zeros((world * blk.shape[0], blk.shape[1]), dtype=torch.int16, device="cuda")
+        ework = torch.empty(device.expand_workspace_bytes(n, nup.unique, True, 0, ds.max_len), dtype=torch.uint8, device="cuda")
+        nd["expand_ms"] = t_ms(lambda: device.expand_unique(gathered, nup, True, 0, ds.max_len, out, table_world=world, work=ework))
+        r["nw_dedup_w%d" % world] = nd
+        del blk, gathered, ework
     print(json.dumps(r))
 
 if __name__ == "__main__":
