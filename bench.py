@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-uniform", action="store_true", help="skip the uniform-peptide leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (T_h, PCIe-inclusive) measurement")
     ap.add_argument("--no-clusterbreak", action="store_true", help="skip the clusterbreak end-to-end run (BASELINE config 5)")
-    ap.add_argument("--plane-bits", type=int, default=0, choices=[0, 12, 16, 32],
+    ap.add_argument("--plane-bits", type=int, default=0, choices=[0, 12, 14, 15, 16, 32],
                     help="0: compare the signatures' exact dictionary codes with as few bit planes as the data needs "
                          "(default); 12 / 16: at least that many code planes; 32: raw signature bits")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per baseline leg")
@@ -315,7 +315,7 @@ def main():
         """roofline object of the compare kernel: algorithmic bytes (with the plane words actually read) /
         HIP-event duration, against the 8 TB/s HBM peak; + the VALU bound that actually binds"""
         k2 = k2_ms * 1e-3
-        planes_row_bytes = 2 * 16 * plane_bits * 4        # two copies x 16 groups x planes x 4 B
+        planes_row_bytes = 2 * 16 * (16 if plane_bits in (14, 15) else plane_bits) * 4   # two copies x 16 groups x planes x 4 B
         T = (wl_n + 127) // 128
         if world == 1:
             bytes_k2 = wl_n * planes_row_bytes + wl_n * wl_n * out_elem   # read the bit planes once + write the N x N (f64, or uint16 counts)
@@ -326,7 +326,12 @@ def main():
         lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
         # 12 / 16 code planes, symmetric mode: the hand-scheduled kernels do all but the diagonal / border tiles
         f64s = "true" if out_elem == 8 else "false"
-        k2_name = ("k_mh_compare_a%d<%s>" % (plane_bits, f64s)) if (world == 1 and plane_bits in (12, 16)) else "k_mh_compare<%s, true, %d>" % (f64s, plane_bits)
+        if world == 1 and plane_bits == 12:
+            k2_name = "k_mh_compare_a12<%s>" % f64s
+        elif world == 1 and plane_bits in (14, 15, 16):      # <float64 output, code bits>: 14 / 15 skip the top planes' step / half step
+            k2_name = "k_mh_compare_a16<%s, %d>" % (f64s, plane_bits)
+        else:
+            k2_name = "k_mh_compare<%s, true, %d>" % (f64s, 16 if plane_bits in (14, 15) else plane_bits)
         traffic = pmc_traffic(k2_name, wl_n) if world == 1 else None
         return {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,

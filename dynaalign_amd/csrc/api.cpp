@@ -452,7 +452,7 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
 static int env_plane_bits() {   // DYNAALIGN_PLANE_BITS: 32 = raw planes, 12 / 16 = at least that many code planes
   const char *e = getenv("DYNAALIGN_PLANE_BITS");
   const int v = e ? atoi(e) : 0;
-  return (v == 32 || v == 16 || v == 12) ? v : 0;
+  return (v == 32 || v == 16 || v == 15 || v == 14 || v == 12) ? v : 0;
 }
 // min_bits: 0 = as few code planes as the data needs, 12 / 16 = at least that many, 32 = raw planes
 static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, int min_bits, void *d_work,
@@ -488,8 +488,8 @@ int da_dev_mh_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_has
   if (n_hash <= 0) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
   if (!d_sig || !d_planes || !plane_bits_out) return fail(DA_ERR_BAD_ARG, "NULL pointer");
   if (ld_sig < n_hash) return fail(DA_ERR_BAD_ARG, "ld_sig (%lld) < n_hash (%d)", (long long)ld_sig, n_hash);
-  if (min_plane_bits != 0 && min_plane_bits != 12 && min_plane_bits != 16 && min_plane_bits != 32)
-    return fail(DA_ERR_BAD_ARG, "min_plane_bits must be 0, 12, 16 or 32 (got %d)", min_plane_bits);
+  if (min_plane_bits != 0 && min_plane_bits != 12 && min_plane_bits != 14 && min_plane_bits != 15 && min_plane_bits != 16 && min_plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "min_plane_bits must be 0, 12, 14, 15, 16 or 32 (got %d)", min_plane_bits);
   if ((reinterpret_cast<uintptr_t>(d_planes) & 15) || planes_words < mh_planes_words(n, n_hash))
     return fail(DA_ERR_BAD_ARG, "bit-plane buffer must be 16-byte aligned and hold da_mh_planes_words(n, n_hash) = %lld words",
                 (long long)mh_planes_words(n, n_hash));
@@ -512,8 +512,8 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
   if (n_hash > 65535)
     return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d)", n_hash);
   if (reinterpret_cast<uintptr_t>(d_planes) & 15) return fail(DA_ERR_BAD_ARG, "bit-plane buffer must be 16-byte aligned");
-  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 16 && plane_bits != 32)
-    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 16 or 32 (got %d)", plane_bits);
+  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 14 && plane_bits != 15 && plane_bits != 16 && plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 14, 15, 16 or 32 (got %d)", plane_bits);
   return launch_mh_compare(d_planes, n, n_hash, row_begin, row_end, symmetric != 0, kind, d_out, ld,
                            static_cast<hipStream_t>(stream), plane_bits);
 }
@@ -843,8 +843,8 @@ int da_dev_mh_compare_shard(const uint32_t *d_planes, int plane_bits, int64_t n,
   const ShardGeom sg = shard_geom(n, world, 128);
   if (ld < sg.W) return fail(DA_ERR_BAD_ARG, "ld (%lld) < da_shard_ld (%lld)", (long long)ld, (long long)sg.W);
   if (reinterpret_cast<uintptr_t>(d_planes) & 15) return fail(DA_ERR_BAD_ARG, "bit-plane buffer must be 16-byte aligned");
-  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 16 && plane_bits != 32)
-    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 16 or 32 (got %d)", plane_bits);
+  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 14 && plane_bits != 15 && plane_bits != 16 && plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 14, 15, 16 or 32 (got %d)", plane_bits);
   if ((int64_t)rank * 128 >= n) return DA_OK;  // this rank owns no rows
   return launch_mh_compare(d_planes, n, n_hash, (int64_t)rank * 128, n, false, DA_OUT_COMPACT, d_local, ld,
                            static_cast<hipStream_t>(stream), plane_bits, world, true, sg.Q, sg.W);

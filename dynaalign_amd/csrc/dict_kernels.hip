@@ -184,8 +184,9 @@ __global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__res
 // hash function h0 + l, so one 64-bit ballot per bit is plane p of two adjacent 32-hash groups.
 // pl = planes kept per group (8, 12 or 16: every id is < 2^pl - 2).  Singletons (0xFFFF in idsT):
 // row copy gets 2^pl - 2, column copy 2^pl - 1 -- they differ in plane 0 only.
+// code_bits <= pl: width of the codes (the singleton codes are 2^code_bits - 2 / - 1; planes code_bits .. pl - 1 come out zero).
 __global__ __launch_bounds__(256) void k_ids_to_planes(const uint16_t *__restrict__ idsT, int64_t ld_ids, int64_t n,
-                                                       int n_hash, int pl, uint32_t *__restrict__ planes) {
+                                                       int n_hash, int pl, int code_bits, uint32_t *__restrict__ planes) {
   __shared__ uint16_t tile[64][66];
   const int64_t i0 = (int64_t)blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(256) void k_ids_to_planes(const uint16_t *__restric
       if (i >= n) break;                         // wave-uniform
       const uint32_t v = tile[lane][sq];
       const bool single = (v == 0xFFFFu) && (h0 + lane < n_hash);
-      const uint32_t va = single ? (1u << pl) - 2u : v;
-      const uint32_t vb = single ? (1u << pl) - 1u : v;
+      const uint32_t va = single ? (1u << code_bits) - 2u : v;
+      const uint32_t vb = single ? (1u << code_bits) - 1u : v;
       uint32_t wa = 0, wb = 0;
       for (int p = 0; p < pl; ++p) {                       // pl is uniform
         const unsigned long long m = __ballot((va >> p) & 1u);
@@ -308,9 +309,12 @@ int launch_mh_dictionary(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n
 }
 
 // planes per group that hold `max_ids` dense ids plus the two singleton codes
+// 14 = the 16-plane operand with 14-bit codes (planes 14 and 15 zero): the hand-scheduled kernel then runs seven two-plane steps
 int mh_plane_bits_for(int max_ids) {
   if (max_ids + 2 <= (1 << 8)) return 8;
   if (max_ids + 2 <= (1 << 12)) return 12;
+  if (max_ids + 2 <= (1 << 14)) return 14;
+  if (max_ids + 2 <= (1 << 15)) return 15;                    // (15: plane 15 zero -- the eighth step drops its second half)
   return 16;
 }
 
@@ -320,7 +324,7 @@ int launch_ids_to_planes(const void *d_work, int64_t n, int n_hash, int plane_bi
   const int64_t ldT = dict_ldT(n);
   const uint16_t *idsT = dict_work(const_cast<void *>(d_work), n, n_hash).idsT;
   hipLaunchKernelGGL(k_ids_to_planes, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, stream, idsT, ldT, n, n_hash,
-                     plane_bits, d_planes);
+                     (plane_bits == 14 || plane_bits == 15) ? 16 : plane_bits, plane_bits, d_planes);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }

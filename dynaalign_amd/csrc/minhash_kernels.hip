@@ -436,11 +436,17 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a12(const uint32_t
 // it through a ring of TWO 20 KiB stages (40 KiB: four workgroups per CU) with five 1 KiB DMA pieces per wave and stage from a
 // wave-uniform SGPR base, and hands the counters over in v64..v95 like k_mh_compare_a12.  Symmetric mode, interior
 // off-diagonal tiles (a12_takes); diagonal / border tiles stay with k_mh_compare<.., 16> on the regular copies.
+#ifndef K2_LOOP_INC_14
+#define K2_LOOP_INC_14 "k2_loop_p14.inc"   // the same block with seven two-plane steps: 14-bit codes, planes 14 / 15 of the operand are zero
+#endif
+#ifndef K2_LOOP_INC_15
+#define K2_LOOP_INC_15 "k2_loop_p15.inc"   // eight steps, the last one on plane 14 only: 15-bit codes
+#endif
 #ifndef K2_LOOP_INC_16
 #define K2_LOOP_INC_16 "k2_loop_p16.inc"
 #endif
 constexpr int K2_A16_TABLE_MAX = 2 * 2 * K2_TILE * 80 / 8;   // doubles that fit the 40 KiB ring
-template <bool F64>
+template <bool F64, int CODE_BITS = 16>
 __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a16(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
                                                                   void *__restrict__ out_v, int64_t ld, int64_t ntiles,
                                                                   int64_t per_xcd) {
@@ -475,20 +481,33 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a16(const uint32_t
     K2_CNT(75) K2_CNT(76) K2_CNT(77) K2_CNT(78) K2_CNT(79) K2_CNT(80) K2_CNT(81) K2_CNT(82) K2_CNT(83) K2_CNT(84) K2_CNT(85)
     K2_CNT(86) K2_CNT(87) K2_CNT(88) K2_CNT(89) K2_CNT(90) K2_CNT(91) K2_CNT(92) K2_CNT(93) K2_CNT(94) K2_CNT(95)
 #undef K2_CNT
-    asm volatile(
+#define K2_A16_OPERANDS                                                                                                                      \
+        : "=v"(c64), "=v"(c65), "=v"(c66), "=v"(c67), "=v"(c68), "=v"(c69), "=v"(c70), "=v"(c71), "=v"(c72), "=v"(c73), "=v"(c74),  \
+          "=v"(c75), "=v"(c76), "=v"(c77), "=v"(c78), "=v"(c79), "=v"(c80), "=v"(c81), "=v"(c82), "=v"(c83), "=v"(c84), "=v"(c85),  \
+          "=v"(c86), "=v"(c87), "=v"(c88), "=v"(c89), "=v"(c90), "=v"(c91), "=v"(c92), "=v"(c93), "=v"(c94), "=v"(c95)  \
+        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh),  \
+          "v"(r120), "v"(r121), "v"(r124)  \
+        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",  \
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",  \
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",  \
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",  \
+          "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",  \
+          "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",  \
+          "v117", "v118", "v119", "v122", "v123"
+    if (CODE_BITS == 14) {
+      asm volatile(
+#include K2_LOOP_INC_14
+          K2_A16_OPERANDS);
+    } else if (CODE_BITS == 15) {
+      asm volatile(
+#include K2_LOOP_INC_15
+          K2_A16_OPERANDS);
+    } else {
+      asm volatile(
 #include K2_LOOP_INC_16
-        : "=v"(c64), "=v"(c65), "=v"(c66), "=v"(c67), "=v"(c68), "=v"(c69), "=v"(c70), "=v"(c71), "=v"(c72), "=v"(c73), "=v"(c74),
-          "=v"(c75), "=v"(c76), "=v"(c77), "=v"(c78), "=v"(c79), "=v"(c80), "=v"(c81), "=v"(c82), "=v"(c83), "=v"(c84), "=v"(c85),
-          "=v"(c86), "=v"(c87), "=v"(c88), "=v"(c89), "=v"(c90), "=v"(c91), "=v"(c92), "=v"(c93), "=v"(c94), "=v"(c95)
-        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh),
-          "v"(r120), "v"(r121), "v"(r124)
-        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",   // m0 is saved in s47 and restored by the block
-          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
-          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
-          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
-          "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",
-          "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
-          "v117", "v118", "v119", "v122", "v123");
+          K2_A16_OPERANDS);
+    }
+#undef K2_A16_OPERANDS
     asm volatile("" : "+v"(r124));                               // lane ids are re-derived from the value that crossed the block
     tid_after = r124 >> 2;
     const uint32_t cnt[32] = {c64, c65, c66, c67, c68, c69, c70, c71, c72, c73, c74, c75, c76, c77, c78, c79,
@@ -1237,8 +1256,10 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                       void *d_out, int64_t ld, hipStream_t stream, int plane_bits, int tile_stride, bool upper_only,
                       int fold_q, int64_t fold_w) {
   if (row_end <= row_begin) return DA_OK;
-  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 16 && plane_bits != 32)
-    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 16 or 32 (got %d)", plane_bits);
+  if (plane_bits != 8 && plane_bits != 12 && plane_bits != 14 && plane_bits != 15 && plane_bits != 16 && plane_bits != 32)
+    return fail(DA_ERR_BAD_ARG, "plane_bits must be 8, 12, 14, 15, 16 or 32 (got %d)", plane_bits);
+  const int code_bits = plane_bits;           // 14 / 15: the 16-plane operand with its top planes zero -- everything but k_mh_compare_a16
+  if (plane_bits == 14 || plane_bits == 15) plane_bits = 16;   // treats it as 16 planes
   const int T = (int)ceil_div(n, K2_TILE);
   const int TR = (int)ceil_div(ceil_div(row_end - row_begin, K2_TILE), tile_stride);
   const int64_t ntiles = count_tiles(TR, T, symmetric);
@@ -1261,10 +1282,10 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                    (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A16_TABLE_MAX) &&
                    (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;
   if (a16) {
-    if (kind == DA_OUT_F64)
-      hipLaunchKernelGGL(k_mh_compare_a16<true>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
-    else
-      hipLaunchKernelGGL(k_mh_compare_a16<false>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
+#define DA_A16(F, B) hipLaunchKernelGGL((k_mh_compare_a16<F, B>), grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd)
+    if (kind == DA_OUT_F64) { if (code_bits == 14) DA_A16(true, 14); else if (code_bits == 15) DA_A16(true, 15); else DA_A16(true, 16); }
+    else { if (code_bits == 14) DA_A16(false, 14); else if (code_bits == 15) DA_A16(false, 15); else DA_A16(false, 16); }
+#undef DA_A16
   }
   // the persistent form of that kernel: >= 2 stages per tile, float64 needs its 4 KiB table (n_hash <= 511)
   // OPT-IN (DYNAALIGN_K2_PERSIST=1): measured slower than one tile per workgroup on MI355X -- 28.8 vs 24.9 ms (float64),

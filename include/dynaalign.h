@@ -175,12 +175,13 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
  * bit-sliced compare does that fraction of the work.  Exact for every input with n <= 131068
  * (at most n/2 repeated values per column fit 16 bits); larger n -- or the never-observed
  * overflow of the dictionary's LDS table -- produce the raw 32-plane operand instead.
- *   min_plane_bits: 0 = as few planes as the data needs; 12 / 16 = at least that many code
- *                   planes; 32 = raw signature bits (no dictionary).
+ *   min_plane_bits: 0 = as few planes as the data needs; 12 / 14 / 15 / 16 = at least that many code
+ *                   bits; 32 = raw signature bits (no dictionary).  (14 / 15 = the 16-plane operand with
+ *                   its top planes zero: the hand-scheduled kernel skips their step / half step.)
  *   d_planes      : 16-byte aligned buffer of planes_words >= da_mh_planes_words(n, n_hash)
  *                   uint32; opaque (blocked in the order the compare kernel stages it).
  *   d_work        : da_mh_planes_workspace_bytes(n, n_hash) bytes of scratch, 256-byte aligned
- *   plane_bits_out: 8, 12, 16 or 32 -- pass it to da_dev_mh_compare[_shard].
+ *   plane_bits_out: 8, 12, 14, 15, 16 or 32 -- pass it to da_dev_mh_compare[_shard].
  * Synchronises `stream` once (reads the dictionary's status words) on the dictionary route.
  * The environment variable DYNAALIGN_PLANE_BITS (12, 16, 32) raises min_plane_bits (debugging aid;
  * it also reaches the host-pointer entry points). */

@@ -37,7 +37,7 @@ def _bits_needed(sig_h):
     for h in range(sig_h.shape[1]):
         _, c = np.unique(sig_h[:, h], return_counts=True)
         most = max(most, int((c >= 2).sum()))
-    return 8 if most + 2 <= 256 else 12 if most + 2 <= 4096 else 16
+    return 8 if most + 2 <= 256 else 12 if most + 2 <= 4096 else 14 if most + 2 <= 16384 else 15 if most + 2 <= 32768 else 16
 
 
 def _planes_both(da, res, off, k, n_hash, seed=12345, min_bits=0):
@@ -46,7 +46,7 @@ def _planes_both(da, res, off, k, n_hash, seed=12345, min_bits=0):
     ds = device.DeviceSequences(res, off)
     sig, pc = device.minhash_signatures(ds, k, n_hash, seeds, min_plane_bits=min_bits)
     _, p32 = device.minhash_signatures(ds, k, n_hash, seeds, raw_planes=True)
-    assert pc.bits in (8, 12, 16) and pc.bits >= min_bits and p32.bits == 32
+    assert pc.bits in (8, 12, 14, 15, 16) and pc.bits >= min_bits and p32.bits == 32
     return ds.n, sig[:, :n_hash].cpu().numpy().view(np.uint32), pc, p32
 
 
@@ -54,7 +54,7 @@ def _planes_both(da, res, off, k, n_hash, seed=12345, min_bits=0):
                                    ("uniform_peptides", 64), ("uniform_peptides", 65), ("uniform_peptides", 1000),
                                    ("h3n2_like", 129), ("h3n2_like", 1500), ("uniform_peptides", 9000)])
 @pytest.mark.parametrize("n_hash", [500, 31, 64])
-@pytest.mark.parametrize("min_bits", [0, 12, 16])
+@pytest.mark.parametrize("min_bits", [0, 12, 14, 15, 16])
 def test_codes_give_the_counts_of_the_raw_signatures(da, gen, n, n_hash, min_bits):
     """8 / 12 / 16 code planes (whatever the data needs, or forced up) == 32 raw planes == numpy"""
     from dynaalign_amd import device, synth, _capi
@@ -228,7 +228,7 @@ def test_crafted_signature_columns(da, n):
 
 @pytest.mark.parametrize("n,n_hash", [(1000, 500), (1153, 70), (2048, 33), (640, 31), (2500, 64), (3001, 129), (1300, 511), (1300, 512),
                                       (5000, 500)])
-@pytest.mark.parametrize("bits", [12, 16])
+@pytest.mark.parametrize("bits", [12, 14, 15, 16])
 def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash, bits):
     """symmetric 12-plane compares run a hand-scheduled stage loop on interior tiles and the compiled kernel on diagonal /
     border tiles.  Three routes, same operand: the one-tile-per-workgroup k_mh_compare_a12 (default), the PERSISTENT kernel
@@ -240,7 +240,7 @@ def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash, bits)
     from dynaalign_amd import device, synth, _capi
     res, off = synth.h3n2_like(n, 20)
     n, sig_h, p12, p32 = _planes_both(da, res, off, 4, n_hash, min_bits=bits)
-    assert p12.bits == bits          # 16: k_mh_compare_a16 on the padded twin of the operand (8 steps per stage, ring of two stages)
+    assert p12.bits == bits          # 16: k_mh_compare_a16 on the padded twin of the operand (8 steps per stage, ring of two stages); 14: its seven-step form
     want = _counts(sig_h) if n <= 3100 else None
     got = {}
     for tag, env in (("persistent", "DYNAALIGN_K2_PERSIST"), ("one_tile", None), ("compiled", "DYNAALIGN_K2_NO_ASM")):

@@ -58,3 +58,23 @@ def test_committed_16_plane_include_is_the_generators_output(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
                           stdout=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p16.inc")).read()
+
+
+@pytest.mark.parametrize("ns,tx,ty", [(16, 0, 0), (1, 5, 11), (2, 15, 15), (3, 7, 8)])
+@pytest.mark.parametrize("bits", [14, 15])
+def test_14_and_15_bit_blocks(ns, tx, ty, bits):
+    """the shortened forms of the 16-plane block: 14 code bits = seven steps (planes 14 / 15 never read), 15 = the eighth step on
+    plane 14 only"""
+    import sim_k2_asm
+    issued, bad = (sim_k2_asm.run14 if bits == 14 else sim_k2_asm.run15)(tx, ty, seed=ns, ns=ns)
+    assert issued == ns and bad == 0
+
+
+@pytest.mark.parametrize("bits", [14, 15])
+def test_committed_14_15_bit_includes_are_the_generators_output(tmp_path, bits):
+    out = tmp_path / "k2_x.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("K2ASM_")}
+    env["K2ASM_PLANES"] = str(bits)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
+                          stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p%d.inc" % bits)).read()

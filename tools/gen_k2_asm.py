@@ -39,11 +39,15 @@ PLANES = int(os.environ.get("K2ASM_PLANES", "12"))   # 16: the block of k_mh_com
 # padding) make the loop's 8-byte operand reads bank-conflict-free with plain immediate offsets (the 64-byte slots of the
 # compiled kernel need an XOR swizzle that an immediate cannot express), a wave's share of a stage is exactly five 1 KiB DMA
 # pieces, and a ring of TWO 20 KiB stages keeps four workgroups per CU.  SGPR-base DMA form, counters out in registers.
-if PLANES == 16:
+# 14: the same block with SEVEN two-plane steps (K2ASM_PLANES=14, k2_loop_p14.inc): column dictionaries of up to 16 382 values need 14 code bits --
+# uniform random 100k peptides: ~15 000 -- so the operand's planes 14 and 15 are zero and the eighth step would OR nothing in.
+# 15: eight steps, the last one on plane 14 only (K2ASM_PLANES=15, k2_loop_p15.inc; uniform random 100k peptides: ~18 000 values per column).
+if PLANES in (14, 15, 16):
     SADDR = 1
     REGOUT = 1
     assert not PERSIST
-SEGS, STEPS = (3, 6) if PLANES == 12 else (5, 8)   # 16-byte units per LDS slot; 2-plane steps per stage
+SEGS, STEPS = (3, 6) if PLANES == 12 else (5, (PLANES + 1) // 2)   # 16-byte units per LDS slot; 2-plane steps per stage
+HALF_LAST = PLANES == 15                                            # the last step's odd plane is zero in the operand: its instruction is left out
 STAGE_BYTES = 256 * SEGS * 16  # 12288 (20480 with the padded 16-plane slots)
 ROW = 16 * SEGS * 16          # byte distance between the lane's rows / columns in LDS: 768 (1280)
 out = []
@@ -138,7 +142,8 @@ def step(k, first, last, cur):
                 e("v_xor_b32 %s, %s, %s" % (d(r, c), ax(r), B[cur][2]))
             else:
                 e("v_bitop3_b32 %s, %s, %s, %s bitop3:0xf6" % (d(r, c), d(r, c), ax(r), B[cur][2]))
-            e("v_bitop3_b32 %s, %s, %s, %s bitop3:0xf6" % (d(r, c), d(r, c), ay(r), B[cur][1]))
+            if not (HALF_LAST and last):
+                e("v_bitop3_b32 %s, %s, %s, %s bitop3:0xf6" % (d(r, c), d(r, c), ay(r), B[cur][1]))
             if c == 7 and not last:
                 e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW + (k + 1) * 8))
         cur = (cur + 1) % 3
@@ -264,7 +269,7 @@ def gen_persistent():
     e("s_mov_b32 m0, s47")
 
 def gen_16():
-    e("// generated by tools/gen_k2_asm.py (K2ASM_PLANES=16) -- do not edit")
+    e("// generated by tools/gen_k2_asm.py (K2ASM_PLANES=%d) -- do not edit" % PLANES)
     e("s_mov_b32 s47, m0")
     if PRIO:
         e("s_setprio %d" % PRIO)
@@ -325,7 +330,7 @@ def gen_16():
 
 if PERSIST:
     gen_persistent()
-elif PLANES == 16:
+elif PLANES in (14, 15, 16):
     gen_16()
 else:
     e("// generated by tools/gen_k2_asm.py -- do not edit")

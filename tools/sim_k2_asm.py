@@ -26,6 +26,22 @@ def run16(tx=5, ty=11, seed=1, ns=16):
     return run_persistent(tx, ty, seed, ntiles=1, ns=ns, inc=INC_16, planes=16, slot_bytes=80, ring=2)
 
 
+INC_14 = os.path.join(os.path.dirname(INC), "k2_loop_p14.inc")
+
+
+def run14(tx=5, ty=11, seed=1, ns=16):
+    """The seven-step form of the 16-plane block (K2ASM_PLANES=14): same padded slots and ring, plane words 14 and 15 never read"""
+    return run_persistent(tx, ty, seed, ntiles=1, ns=ns, inc=INC_14, planes=14, slot_bytes=80, ring=2)
+
+
+INC_15 = os.path.join(os.path.dirname(INC), "k2_loop_p15.inc")
+
+
+def run15(tx=5, ty=11, seed=1, ns=16):
+    """15 code bits (K2ASM_PLANES=15): eight steps, the last one on plane 14 only -- plane word 15 is read but never used"""
+    return run_persistent(tx, ty, seed, ntiles=1, ns=ns, inc=INC_15, planes=15, slot_bytes=80, ring=2)
+
+
 def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, slot_bytes=48, ring=3):
     """The block of the persistent kernel (K2ASM_PERSIST=1), executed `ntiles` times in a row on one LDS image, the
     way k_mh_compare_p12 calls it: flags first / has-next, ring phase advancing by ns stages per tile, the next tile's
