@@ -459,7 +459,11 @@ def main():
             cnt16 = out.view(-1).view(torch.int16)[:n * n].view(n, n)          # the f64 result buffer is free here: reuse its first 20 GB
             values = np.arange(n_hash + 1, dtype=np.float64) / n_hash
 
-            def run_edges():
+            eprobe = device.UniquePlan(ds.residues, ds.offsets, n, ds.total)
+            edges_dedup = sharding.dedup_worth(n, eprobe.unique, False, n_hash) and eprobe.unique <= 65536
+            del eprobe
+
+            def run_edges_direct():
                 pl = signatures_and_planes()
                 device.mh_compare(pl, n, n_hash, 0, n, True, _capi.DA_OUT_COMPACT, out=cnt16)
                 h = device.upper_histogram(cnt16, n, n_hash + 1).cpu().numpy().astype(np.uint64)
@@ -468,6 +472,21 @@ def main():
                 m = int(h[keep].sum()) + n
                 ei, ej, evv, c = device.extract_edges(cnt16, n, keep, m)
                 return thr, ei, ej, evv, c
+
+            def run_edges_dedup():
+                # duplicates collapsed: K1 / K1b / K2 on the unique strings, then histogram + extraction read the n x n count matrix
+                # through the plan's row map (da_dev_unique_rows) -- no n x n matrix at all
+                up = device.UniquePlan(ds.residues, ds.offsets, n, ds.total)
+                _, upl = device.minhash_signatures(sharding.UniqueSequences(up, ds.total, ds.max_len), k, n_hash, d_seeds)
+                table = device.unique_table(upl, up.unique, n_hash)
+                rows = device.unique_rows(table, up)
+                h = device.upper_histogram_rows(rows, up, n_hash + 1).cpu().numpy().astype(np.uint64)
+                thr = da.quantile_type7(h, values, 0.8)
+                keep = (~(values < thr)) & (np.arange(n_hash + 1) != 0)
+                m = int(h[keep].sum()) + n
+                ei, ej, evv, c = device.extract_edges_rows(rows, up, keep, m)
+                return thr, ei, ej, evv, c
+            run_edges = run_edges_dedup if edges_dedup else run_edges_direct
         else:
             eplan = sharding.Plan(n, rank, world, sharding.MH_TILE)
 
@@ -485,8 +504,10 @@ def main():
         if world > 1:
             dist.all_reduce(tot)
         line["edges"] = {"workload": "similarityMH k=4 n_hash=500 + quantile(S[upper.tri(S)], 0.8) threshold -> edge list "
-                                     "(R/clusterbreak.R:219-221), same %d peptides; %s" % (n, "one GPU: symmetric uint16 compare -> histogram -> "
+                                     "(R/clusterbreak.R:219-221), same %d peptides; %s" % (n, "one GPU: symmetric uint16 compare (on the unique strings when "
+                                     "duplicates are collapsed, read back through the plan's row map) -> histogram -> "
                                      "quantile -> edges" if world == 1 else "edges stay distributed over the ranks"),
+                         "dedup": bool(world == 1 and edges_dedup),
                          "value": pairs_mh / t_e, "unit": "pairs/s", "ms": t_e * 1e3, "threshold": thr,
                          "edges_total": int(tot.item()), "edge_list_bytes": int(tot.item()) * 10}
         del ei, ej, evv

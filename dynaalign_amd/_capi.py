@@ -52,6 +52,10 @@ SIGNATURES = {
     "da_dev_shards_to_table": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_nw_unique_rows": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "da_dev_expand_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
+    "da_dev_unique_rows_bytes": (_sz, [_i64, _i64]),
+    "da_dev_unique_rows": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "da_dev_upper_histogram_rows": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "da_dev_extract_edges_rows": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "da_dev_expand_unique": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp, _i64, _vp]),
     "da_dev_nw_encode": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "da_dev_nw": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),

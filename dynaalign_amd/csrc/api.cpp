@@ -689,6 +689,19 @@ int da_dev_expand_unique(const uint16_t *d_table, int64_t ld_table, int table_wo
                               nw_max_len, d_F, plan->d_ufirst, U, nullptr, nullptr, table_world, rows_local);
 }
 
+size_t da_dev_unique_rows_bytes(int64_t n, int64_t unique) {
+  if (n <= 0 || unique <= 0) return 256;
+  return (size_t)unique * (size_t)(ceil_div(n, 8) * 8) * 2;
+}
+
+int da_dev_unique_rows(const uint16_t *d_table, int64_t ld_table, const da_unique_plan *plan, uint16_t *d_rows, void *stream) {
+  if (!plan || plan->struct_size < sizeof(da_unique_plan) || !plan->d_uidx || !plan->d_ufirst) return fail(DA_ERR_BAD_ARG, "bad da_unique_plan");
+  if (!d_table || !d_rows) return fail(DA_ERR_BAD_ARG, "NULL device pointer");
+  if (ld_table < plan->unique) return fail(DA_ERR_BAD_ARG, "ld_table < unique");
+  return launch_gather_columns(d_table, ld_table, plan->d_uidx, plan->d_ufirst, plan->n, plan->unique, d_rows, ceil_div(plan->n, 8) * 8, true,
+                               static_cast<hipStream_t>(stream));
+}
+
 int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int rank, int world,
                           uint16_t *d_out, int64_t ld, void *stream) {
   if (!plan || plan->struct_size < sizeof(da_unique_plan) || !plan->d_ubytes || !plan->d_uoffsets || !plan->d_ufirst || !plan->d_minfirst ||
@@ -906,6 +919,27 @@ int da_dev_upper_histogram(const uint16_t *d_compact, int64_t ld, int64_t n, int
   if (!d_compact || !d_hist || ld < n || nbins <= 0 || nbins > 65536) return fail(DA_ERR_BAD_ARG, "bad histogram arguments");
   return launch_upper_histogram(d_compact, ld, n, nbins, reinterpret_cast<unsigned long long *>(d_hist),
                                 static_cast<hipStream_t>(stream));
+}
+
+// the same two steps reading the n x n count matrix THROUGH a row map (row i = row d_rowmap[i] of d_rows: da_dev_unique_rows'
+// table with the plan's d_uidx) -- the duplicate rows are never materialised
+int da_dev_upper_histogram_rows(const uint16_t *d_rows, int64_t ld, const int32_t *d_rowmap, int64_t n, int nbins, uint64_t *d_hist,
+                                void *stream) {
+  if (n <= 0) return DA_OK;
+  if (!d_rows || !d_rowmap || !d_hist || ld < n || nbins <= 0 || nbins > 65536) return fail(DA_ERR_BAD_ARG, "bad histogram arguments");
+  return launch_upper_histogram(d_rows, ld, n, nbins, reinterpret_cast<unsigned long long *>(d_hist), static_cast<hipStream_t>(stream), 0, 0,
+                                d_rowmap);
+}
+
+int da_dev_extract_edges_rows(const uint16_t *d_rows, int64_t ld, const int32_t *d_rowmap, int64_t n, const uint8_t *d_keep, int nbins,
+                              int include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity, uint64_t *d_count,
+                              void *stream) {
+  if (n <= 0) return DA_OK;
+  if (!d_rows || !d_rowmap || !d_keep || !d_i || !d_j || !d_v || !d_count || ld < n || nbins <= 0 || nbins > 65536 || capacity < 0)
+    return fail(DA_ERR_BAD_ARG, "bad edge-extraction arguments");
+  if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "edge indices are int32");
+  return launch_extract_edges(d_rows, ld, n, d_keep, nbins, include_diagonal != 0, d_i, d_j, d_v, capacity,
+                              reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream), 0, 0, d_rowmap);
 }
 
 // The same two steps on ONE RANK'S folded shard block (da_dev_mh_compare_shard output): every unordered

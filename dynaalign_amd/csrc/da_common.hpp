@@ -162,10 +162,15 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
 // bytes of the column-gathered table (d_F) that switches launch_expand_unique to its two streaming passes; 0 = shape not covered
 size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, int n_hash, int nw_max_len);
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
-                           hipStream_t stream, int rank = 0, int world = 0);
+                           hipStream_t stream, int rank = 0, int world = 0, const int32_t *d_rowmap = nullptr);
 int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,
                          bool include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
-                         unsigned long long *d_count, hipStream_t stream, int rank = 0, int world = 0);
+                         unsigned long long *d_count, hipStream_t stream, int rank = 0, int world = 0,
+                         const int32_t *d_rowmap = nullptr);
+// minhash_kernels.hip: F[r][j] = D[r][uidx[j]] for the columns right of (from_first_tile: from) the 128-tile of r's first occurrence
+int launch_gather_columns(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, const int32_t *d_ufirst, int64_t n, int64_t U,
+                          uint16_t *d_F, int64_t ld_f, bool from_first_tile, hipStream_t stream, int table_world = 1,
+                          int64_t table_rows_local = 0);
 int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream);
 int launch_acc_counts(uint32_t *d_acc, const uint16_t *d_cnt, int64_t count, bool first, hipStream_t stream);
 int launch_counts32_to_f64(const uint32_t *d_acc, double *d_out, int64_t count, int n_hash, hipStream_t stream);

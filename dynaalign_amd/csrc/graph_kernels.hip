@@ -34,7 +34,9 @@ __device__ __forceinline__ void tri_tile(int64_t L, int T, int &ti, int &tj) {
 
 // Where the count matrix lives: a dense n x n uint16 matrix (world == 0), or one rank's folded
 // shard block (ShardGeom; rank p holds tile rows q*world + p right of the diagonal).
-struct Layout { ShardGeom g; int rank; int sharded; };
+// rowmap != NULL (dense layout only): row i of the matrix is row rowmap[i] of `m` -- the column-gathered table of the UNIQUE strings
+// (k_gather_columns: m[r][j] = count(unique r, sequence j)), i.e. the n x n count matrix without materialising its duplicate rows.
+struct Layout { ShardGeom g; int rank; int sharded; const int32_t *rowmap; };
 
 // block id -> upper tile (ti, tj) and the offsets that turn global (i, j) into an element index
 __device__ __forceinline__ bool locate_tile(const Layout &lay, int64_t L, int T, int &ti, int &tj, int64_t &roff, int64_t &coff) {
@@ -56,7 +58,9 @@ __device__ __forceinline__ bool locate_tile(const Layout &lay, int64_t L, int T,
 struct TileRows { uint32_t w[8][4]; };   // [pass][4 dwords = 8 counts]; 0xFFFF marks "not an element"
 
 __device__ __forceinline__ void load_tile(const uint16_t *__restrict__ m, int64_t ld, int64_t n, int64_t I0, int64_t J0,
-                                          int64_t roff, int64_t coff, bool diag_tile, bool keep_diagonal, TileRows &t) {
+                                          int64_t roff, int64_t coff, bool diag_tile, bool keep_diagonal, TileRows &t,
+                                          const int32_t *__restrict__ rowmap) {
+  auto row_of = [&](int64_t i) -> int64_t { return rowmap ? (int64_t)rowmap[i] : i + roff; };
   const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 8;
   const int64_t j0 = J0 + tc;
   const bool inside = I0 + G_TILE <= n && J0 + G_TILE <= n;
@@ -64,7 +68,7 @@ __device__ __forceinline__ void load_tile(const uint16_t *__restrict__ m, int64_
   if (inside && aligned && !diag_tile) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(m + (I0 + 16 * p + tr + roff) * ld + j0 + coff);
+      const uint4 v = *reinterpret_cast<const uint4 *>(m + row_of(I0 + 16 * p + tr) * ld + j0 + coff);
       t.w[p][0] = v.x; t.w[p][1] = v.y; t.w[p][2] = v.z; t.w[p][3] = v.w;
     }
     return;
@@ -76,8 +80,8 @@ __device__ __forceinline__ void load_tile(const uint16_t *__restrict__ m, int64_
     for (int e = 0; e < 8; e += 2) {
       uint32_t lo = 0xFFFFu, hi = 0xFFFFu;
       const int64_t j = j0 + e;
-      if (i < n && j < n && (j > i || (keep_diagonal && j == i))) lo = m[(i + roff) * ld + j + coff];
-      if (i < n && j + 1 < n && (j + 1 > i || (keep_diagonal && j + 1 == i))) hi = m[(i + roff) * ld + j + 1 + coff];
+      if (i < n && j < n && (j > i || (keep_diagonal && j == i))) lo = m[row_of(i) * ld + j + coff];
+      if (i < n && j + 1 < n && (j + 1 > i || (keep_diagonal && j + 1 == i))) hi = m[row_of(i) * ld + j + 1 + coff];
       t.w[p][e >> 1] = lo | (hi << 16);
     }
   }
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(G_THREADS) void k_upper_histogram(const uint16_t *_
     int64_t roff, coff;
     if (!locate_tile(lay, L, T, ti, tj, roff, coff)) continue;             // block-uniform
     TileRows t;
-    load_tile(m, ld, n, (int64_t)ti * G_TILE, (int64_t)tj * G_TILE, roff, coff, ti == tj, false, t);
+    load_tile(m, ld, n, (int64_t)ti * G_TILE, (int64_t)tj * G_TILE, roff, coff, ti == tj, false, t, lay.rowmap);
     unsigned z = 0;
 #pragma unroll
     for (int p = 0; p < 8; ++p)
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
   if (!locate_tile(lay, blockIdx.x, T, ti, tj, roff, coff)) return;       // block-uniform
   const int64_t I0 = (int64_t)ti * G_TILE, J0 = (int64_t)tj * G_TILE;
   TileRows t;
-  load_tile(m, ld, n, I0, J0, roff, coff, ti == tj, include_diagonal != 0, t);
+  load_tile(m, ld, n, I0, J0, roff, coff, ti == tj, include_diagonal != 0, t, lay.rowmap);
   unsigned long long kept = 0;                               // bit 8*pass + e
 #pragma unroll
   for (int p = 0; p < 8; ++p)
@@ -186,21 +190,22 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
 
 }  // namespace
 
-static Layout make_layout(int64_t n, int rank, int world) {
+static Layout make_layout(int64_t n, int rank, int world, const int32_t *rowmap = nullptr) {
   Layout lay;
   lay.g = shard_geom(n, world > 0 ? world : 1, G_TILE);
   lay.rank = rank;
   lay.sharded = world > 0 ? 1 : 0;
+  lay.rowmap = world > 0 ? nullptr : rowmap;
   return lay;
 }
 
 // world == 0: d_m is a dense n x n matrix (ld >= n); world >= 1: d_m is rank's folded shard block (ld >= W)
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
-                           hipStream_t stream, int rank, int world) {
+                           hipStream_t stream, int rank, int world, const int32_t *d_rowmap) {
   if (n <= 1) return DA_OK;
   if (nbins > 65535) return fail(DA_ERR_UNSUPPORTED, "histogram of uint16 counts: at most 65535 bins (value 65535 is reserved)");
   const int T = (int)ceil_div(n, G_TILE);
-  const Layout lay = make_layout(n, rank, world);
+  const Layout lay = make_layout(n, rank, world, d_rowmap);
   const int64_t tiles = world > 0 ? (int64_t)lay.g.Q * T : (int64_t)T * (T + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * 16);
@@ -211,11 +216,11 @@ int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins
 
 int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8_t *d_keep, int nbins,
                          bool include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity,
-                         unsigned long long *d_count, hipStream_t stream, int rank, int world) {
+                         unsigned long long *d_count, hipStream_t stream, int rank, int world, const int32_t *d_rowmap) {
   if (n <= 0) return DA_OK;
   if (nbins > 65535) return fail(DA_ERR_UNSUPPORTED, "edge extraction from uint16 counts: at most 65535 bins (value 65535 is reserved)");
   const int T = (int)ceil_div(n, G_TILE);
-  const Layout lay = make_layout(n, rank, world);
+  const Layout lay = make_layout(n, rank, world, d_rowmap);
   const int64_t tiles = world > 0 ? (int64_t)lay.g.Q * T : (int64_t)T * (T + 1) / 2;
   if (tiles > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "matrix too large for one launch");
   hipLaunchKernelGGL(k_extract_edges, dim3((unsigned)tiles), dim3(G_THREADS), 0, stream, d_m, ld, n, d_keep, nbins,

@@ -1654,7 +1654,7 @@ constexpr int GC_THREADS = 1024;
 // registers while the current one is gathered out of LDS (U <= 65536 -> at most 8 16-byte units per thread)
 __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                                const int32_t *__restrict__ ufirst, int n, int U, uint16_t *__restrict__ F,
-                                                               int64_t ld_f, TableRows trows) {
+                                                               int64_t ld_f, TableRows trows, int from_first_tile) {
   extern __shared__ __attribute__((aligned(16))) uint16_t gc_row[];   // ld_d entries
   const int units = (int)(ld_d >> 3);
   uint4 pre[8];
@@ -1669,7 +1669,7 @@ __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *_
   int r = blockIdx.x;
   if (r < U) GC_FETCH(r)
   const int2 *u2 = reinterpret_cast<const int2 *>(uidx);
-  const int j2_end = n >> 1;                                         // (an odd last column is a border column)
+  const int j2_end = n >> 1;                                         // column pairs; an odd last column is written by itself below
   for (; r < U; r += gridDim.x) {
     __syncthreads();                                                 // the previous row's gather has left the LDS row
     uint4 *dst = reinterpret_cast<uint4 *>(gc_row);
@@ -1680,12 +1680,13 @@ __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *_
     }
     __syncthreads();
     if (r + (int)gridDim.x < U) GC_FETCH(r + (int)gridDim.x)
-    const int j_begin = ((ufirst[r] >> 7) + 1) << 7;                 // first column of the tile right of r's first occurrence:
+    const int j_begin = ((ufirst[r] >> 7) + (from_first_tile ? 0 : 1)) << 7;   // first column of the tile right of r's first occurrence:
     uint32_t *frow = reinterpret_cast<uint32_t *>(F + (int64_t)r * ld_f);   // interior tiles never read this row left of it
     for (int j2 = (j_begin >> 1) + threadIdx.x; j2 < j2_end; j2 += GC_THREADS) {
       const int2 c = u2[j2];
       __builtin_nontemporal_store((uint32_t)gc_row[c.x] | ((uint32_t)gc_row[c.y] << 16), frow + j2);
     }
+    if ((n & 1) && threadIdx.x == 0 && n - 1 >= j_begin) F[(int64_t)r * ld_f + n - 1] = gc_row[uidx[n - 1]];   // odd n: the last column
   }
 #undef GC_FETCH
 }
@@ -1736,6 +1737,29 @@ size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, i
   return (size_t)U * (size_t)(ceil_div(n, 8) * 8) * 2;
 }
 
+int launch_gather_columns(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, const int32_t *d_ufirst, int64_t n, int64_t U,
+                          uint16_t *d_F, int64_t ld_f, bool from_first_tile, hipStream_t stream, int table_world, int64_t table_rows_local) {
+  if (U < 1 || U > 65536 || (ld_d & 7) || ld_d > 65536 || (reinterpret_cast<uintptr_t>(d_D) & 15) || (ld_f & 1))
+    return fail(DA_ERR_UNSUPPORTED, "column gather: at most 65536 unique strings, 16-byte aligned table rows");
+  const TableRows trows{table_world, table_rows_local};
+  const size_t row_bytes = (size_t)ld_d * 2;
+  static std::atomic<int> gc_cus;
+  if (!gc_cus.load()) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    DA_HIP_TRY(hipGetDevice(&dev));
+    DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_columns), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
+    gc_cus.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+  }
+  const int gc_wg = row_bytes <= 40 * 1024 ? 2 : 1;                    // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
+  const int64_t gc_grid = std::min<int64_t>(U, (int64_t)gc_cus.load() * gc_wg);
+  hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)gc_grid), dim3(GC_THREADS), row_bytes, stream, d_D, ld_d, d_uidx, d_ufirst, (int)n,
+                     (int)U, d_F, ld_f, trows, from_first_tile ? 1 : 0);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
 int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
                          void *d_out, int64_t ld, hipStream_t stream, int nw_max_len, uint16_t *d_F, const int32_t *d_ufirst, int64_t U,
                          hipEvent_t after_gather, hipEvent_t after_rows, int table_world, int64_t table_rows_local) {
@@ -1754,24 +1778,8 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
                     (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
   if (fast) {
     const int64_t ld_f = ceil_div(n, 8) * 8;
-    const size_t row_bytes = (size_t)ld_d * 2;
-    static bool attr_done = false;   // (idempotent; a race sets the same value twice)
-    if (!attr_done) {
-      DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_columns), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
-      attr_done = true;
-    }
-    static std::atomic<int> gc_cus;
-    if (!gc_cus.load()) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      DA_HIP_TRY(hipGetDevice(&dev));
-      DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-      gc_cus.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-    }
-    const int gc_wg = row_bytes <= 40 * 1024 ? 2 : 1;                  // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
-    const int64_t gc_grid = std::min<int64_t>(U, (int64_t)gc_cus.load() * gc_wg);
-    hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)gc_grid), dim3(GC_THREADS), row_bytes, stream, d_D, ld_d, d_uidx, d_ufirst, (int)n,
-                       (int)U, d_F, ld_f, trows);
+    int rc_g = launch_gather_columns(d_D, ld_d, d_uidx, d_ufirst, n, U, d_F, ld_f, false, stream, table_world, table_rows_local);
+    if (rc_g != DA_OK) return rc_g;
     if (after_gather) DA_HIP_TRY(hipEventRecord(after_gather, stream));
     const int T128 = (int)ceil_div(n, 128);
     const int64_t t128 = (int64_t)T128 * (T128 + 1) / 2, px = ceil_div(t128, 8);

@@ -206,6 +206,47 @@ def extract_edges(compact, n, keep, capacity, include_diagonal=True):
     return ei, ej, ev, cnt
 
 
+def unique_table(planes, unique, n_hash):
+    """symmetric uint16 count table of the plan's unique strings (K2 on `unique` rows) with 16-byte aligned rows -- what
+    unique_rows / expand_unique read in 16-byte units"""
+    ld = -(-int(unique) // 8) * 8
+    buf = torch.empty((int(unique), ld), dtype=torch.int16, device=planes.device)
+    return mh_compare(planes, int(unique), n_hash, 0, int(unique), True, DA_OUT_COMPACT, out=buf)
+
+
+def unique_rows(table, plan, out=None):
+    """the n x n uint16 matrix without its duplicate rows (da_dev_unique_rows): [unique][ceil8(n)] int16; row i of the full matrix
+    = row uidx[i] of it for the columns j >= i"""
+    lib = _capi.load()
+    ld = -(-plan.n // 8) * 8
+    if out is None:
+        out = torch.empty((plan.unique, ld), dtype=torch.int16, device=table.device)
+    _capi.check(lib.da_dev_unique_rows(table.data_ptr(), table.stride(0), plan.ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def upper_histogram_rows(rows, plan, nbins):
+    """upper_histogram of the full matrix read through the plan's row map"""
+    hist = torch.zeros(nbins, dtype=torch.int64, device=rows.device)
+    _capi.check(_capi.load().da_dev_upper_histogram_rows(rows.data_ptr(), rows.stride(0), plan.c.d_uidx, plan.n, int(nbins),
+                                                         hist.data_ptr(), _stream()))
+    return hist
+
+
+def extract_edges_rows(rows, plan, keep, capacity, include_diagonal=True):
+    """extract_edges of the full matrix read through the plan's row map"""
+    dev = rows.device
+    keep_t = torch.as_tensor(np.ascontiguousarray(keep, np.uint8)).to(dev)
+    ei = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    ej = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    ev = torch.empty(max(capacity, 1), dtype=torch.int16, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    _capi.check(_capi.load().da_dev_extract_edges_rows(rows.data_ptr(), rows.stride(0), plan.c.d_uidx, plan.n, keep_t.data_ptr(),
+                                                       keep_t.numel(), 1 if include_diagonal else 0, ei.data_ptr(), ej.data_ptr(),
+                                                       ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream()))
+    return ei, ej, ev, cnt
+
+
 def similarity_mh(ds, k, n_hash, seeds, out=None):
     """similarityMH (src/minHash.cpp:119-188) on a device-resident set, one C call: K1 + K1b + K2, with byte-identical
     sequences collapsed first when that pays (da_dev_similarity_mh).  Returns the (n, n) float64 tensor."""

@@ -254,6 +254,17 @@ int da_dev_shards_to_table(const void *d_gathered, int64_t ld_g, int64_t n, int 
  * must have been built on the ENCODED residues (da_dev_nw_encode).  Sequences of 1..64 residues, penalties >= 0. */
 int da_dev_nw_unique_rows(const da_unique_plan *plan, int64_t max_len, int matrix_id, int gap_open, int gap_ext, int rank, int world,
                           uint16_t *d_out, int64_t ld, void *stream);
+/* the n x n uint16 matrix WITHOUT its duplicate rows: d_rows[r][j] = table[r][u(j)] for every unique string r and every sequence j from
+ * the 128-column tile of r's first occurrence on ([unique][ceil8(n)] uint16, da_dev_unique_rows_bytes; natural-row-order table of at most
+ * 65536 strings).  Row i of the full matrix is row plan->d_uidx[i] of it for every j >= i: exactly what the *_rows variants of the
+ * histogram / edge-extraction calls below read (the threshold + edge list of the duplicate route, with no n x n matrix at all). */
+size_t da_dev_unique_rows_bytes(int64_t n, int64_t unique);
+int da_dev_unique_rows(const uint16_t *d_table, int64_t ld_table, const da_unique_plan *plan, uint16_t *d_rows, void *stream);
+int da_dev_upper_histogram_rows(const uint16_t *d_rows, int64_t ld, const int32_t *d_rowmap, int64_t n, int nbins, uint64_t *d_hist,
+                                void *stream);
+int da_dev_extract_edges_rows(const uint16_t *d_rows, int64_t ld, const int32_t *d_rowmap, int64_t n, const uint8_t *d_keep, int nbins,
+                              int include_diagonal, int32_t *d_i, int32_t *d_j, uint16_t *d_v, int64_t capacity, uint64_t *d_count,
+                              void *stream);
 /* dense float64 n x n result from the table of the unique strings: out[i][j] = value(table[u(min(i,j))][u(max(i,j))]), value = count / n_hash
  * (is_nw = 0) or matches / length (is_nw = 1, nw_max_len = longest sequence).  table_world = 1: row r of the table is row r; > 1: the
  * table is the all-gathered row blocks of cyclic 128-row units (rank p computed units p, p + world, ...; every block holds

@@ -160,3 +160,44 @@ def test_odd_leading_dimension_and_unaligned_output(da, small_n_route):
         torch.cuda.synchronize()
         assert device.mh_last_route()["dedup"]
         assert same(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("n_draw,n_single", [(400, 100), (900, 401)])
+def test_threshold_and_edges_through_the_row_map(da, n_draw, n_single):
+    """SURVEY 8(f)-1 on the duplicate route: histogram + edge extraction read the n x n count matrix through the plan's row map
+    (da_dev_unique_rows + *_rows calls) -- identical histogram and identical edge set to the dense uint16 matrix"""
+    import torch
+    from dynaalign_amd import device, _capi
+    import dynaalign_amd as da_
+    rng = np.random.RandomState(n_draw)
+    seqs = duplicated_set(rng, 80, n_draw, n_single, 10, 22)
+    n, n_hash, k = len(seqs), 120, 3
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(res, off)
+    seeds = da_.hash_family_seeds(12345, n_hash)
+    # dense reference on the device: all n rows
+    _, planes = device.minhash_signatures(ds, k, n_hash, seeds)
+    dense = device.mh_compare(planes, n, n_hash, kind=_capi.DA_OUT_COMPACT)
+    h_dense = device.upper_histogram(dense, n, n_hash + 1).cpu().numpy()
+    # duplicate route
+    up = device.UniquePlan(ds.residues, ds.offsets, ds.n, ds.total)
+    from dynaalign_amd.sharding import UniqueSequences
+    _, uplanes = device.minhash_signatures(UniqueSequences(up, ds.total, ds.max_len), k, n_hash, seeds)
+    table = device.unique_table(uplanes, up.unique, n_hash)
+    rows = device.unique_rows(table, up)
+    h_rows = device.upper_histogram_rows(rows, up, n_hash + 1).cpu().numpy()
+    assert np.array_equal(h_rows, h_dense)
+    cs = np.cumsum(h_dense[::-1])[::-1]
+    thr_bin = int(np.argmax(cs <= 0.2 * cs[0])) or 1
+    keep = np.zeros(n_hash + 1, np.uint8)
+    keep[max(thr_bin, 1):] = 1
+    cap = int(h_dense[keep != 0].sum()) + n
+    got = device.extract_edges_rows(rows, up, keep, cap)
+    want = device.extract_edges(dense, n, keep, cap)
+    def as_set(t):
+        c = int(t[3].item())
+        a = torch.stack([t[0][:c].long(), t[1][:c].long(), t[2][:c].long() & 0xFFFF], 1).cpu().numpy()
+        return c, a[np.lexsort((a[:, 1], a[:, 0]))]
+    cg, ag = as_set(got)
+    cw, aw = as_set(want)
+    assert cg == cw == cap and np.array_equal(ag, aw)
