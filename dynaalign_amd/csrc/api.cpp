@@ -523,7 +523,8 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
 // sequences are duplicates the pipeline runs on the table of U unique strings (the plan of the NW route: nw_kernels.hip
 // "duplicate sequences"; MinHash similarity IS symmetric, so the plain symmetric compare on U rows does) -- K2's work shrinks by
 // (U/n)^2 -- and the n x n matrix is an index expansion of the U x U count table (launch_expand_unique's two streaming passes,
-// 5.7 TB/s of stores).  Exact.  Otherwise (uniform peptides: nothing to collapse), or when the expansion's fast passes do not cover the shape
+// 5.7 TB/s of stores).  Exact.  Taken when at most 60 % of the sequences are unique (below that K2's saving outweighs the expansion);
+// otherwise (uniform peptides: nothing to collapse), or when the expansion's fast passes do not cover the shape
 // (U > 65536, n_hash > 2047, n < 2048), the direct kernels run.  Synchronises `stream` (K1b reads the dictionary sizes back).
 // DYNAALIGN_MH_NO_DEDUP=1 switches the route off.
 struct MhRoute { int64_t n = 0, unique = 0; int taken = 0, plane_bits = 0; float ms[6] = {0, 0, 0, 0, 0, 0}; };   // plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles
@@ -557,7 +558,9 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     DA_HIP_TRY(hipStreamSynchronize(stream));
     U = (int64_t)M + S;
     route.unique = U;
-    take = U > 0 && U * 100 <= n * 85 && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
+    // K2 on U rows + column gather + expansion (0.5 + 1.6 f + 22 f^2 + 4.1 f + 14.4 ms at N = 100k, f = U / n) against K1 + K1b + K2 with its
+    // own float64 stores (27.2 ms): the route pays below f = 0.63
+    take = U > 0 && U * 100 <= n * 60 && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
     if (take && (rc = launch_nw_dedup_build(d_res, d_off, n, U, p, stream)) != DA_OK) return rc;
   }
   DA_HIP_TRY(hipEventRecord(ev[1], stream));

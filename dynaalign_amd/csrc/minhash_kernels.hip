@@ -1744,13 +1744,15 @@ int launch_gather_columns(const uint16_t *d_D, int64_t ld_d, const int32_t *d_ui
   const TableRows trows{table_world, table_rows_local};
   const size_t row_bytes = (size_t)ld_d * 2;
   static std::atomic<int> gc_cus;
-  if (!gc_cus.load()) {
-    int dev = 0;
+  static std::atomic<uint64_t> gc_attr_done;                           // per device: the kernel may use a 128 KiB dynamic LDS row
+  int dev = 0;
+  DA_HIP_TRY(hipGetDevice(&dev));
+  if (!((gc_attr_done.load() >> (dev & 63)) & 1u)) {
     hipDeviceProp_t prop;
-    DA_HIP_TRY(hipGetDevice(&dev));
     DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
     DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_columns), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
     gc_cus.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    gc_attr_done.fetch_or(1ull << (dev & 63));
   }
   const int gc_wg = row_bytes <= 40 * 1024 ? 2 : 1;                    // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
   const int64_t gc_grid = std::min<int64_t>(U, (int64_t)gc_cus.load() * gc_wg);

@@ -240,13 +240,14 @@ def unique_table_row(r, world, unique):
 
 
 def dedup_worth(n, unique, is_nw, n_hash=0, max_len=0, min_n=2048):
-    """the rule of the single-GPU routes: >= 15 % duplicates and a shape the two expansion passes cover"""
+    """the rule of the single-GPU routes: few enough unique strings (NW: <= 85 %, MinHash: <= 60 %) and a shape the two expansion
+    passes cover"""
     from . import device
     import os
     min_n = int(os.environ.get("DYNAALIGN_NW_DEDUP_MIN_N" if is_nw else "DYNAALIGN_MH_DEDUP_MIN_N", min_n))
     if os.environ.get("DYNAALIGN_NW_NO_DEDUP" if is_nw else "DYNAALIGN_MH_NO_DEDUP"):
         return False
-    if n < min_n or unique * 100 > n * 85:
+    if n < min_n or unique * 100 > n * (85 if is_nw else 60):    # NW: the DP shrinks by ~(U/n)^2 of 466 ms; MinHash: pays below U = 0.63 n
         return False
     if is_nw and not (1 <= max_len <= 64):
         return False
