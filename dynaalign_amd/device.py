@@ -289,10 +289,6 @@ class UniquePlan:
     def ptr(self):
         return ctypes.addressof(self.c)
 
-    def unique_sequences(self, total):
-        """DeviceSequences-like view (residues / offsets / n / total / max_len left to the caller) of the unique strings"""
-        return self.c.d_ubytes, self.c.d_uoffsets
-
 
 def shards_to_table(gathered, ld_g, n, world, value_bits, out=None):
     """gathered MinHash shards (uint16 blocks: value_bits = 0; packed: their bit count) -> symmetric uint16 table [n][ld]"""

@@ -218,7 +218,6 @@ class UniqueSequences:
     """the plan's unique strings as a DeviceSequences look-alike (tensor views into the plan's workspace)"""
 
     def __init__(self, uplan, total, max_len):
-        from . import device  # noqa: F401
         w = uplan.work
         base = w.data_ptr()
         bo, oo = uplan.c.d_ubytes - base, uplan.c.d_uoffsets - base

@@ -44,7 +44,9 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 1
+/* 2: the folded shard layout changed (da_shard_ld = ceil8(n) + world * 128, back-aligned rows start at column world * 128) and the
+ *    duplicate-route / multi-device entry points were added; every round-1 entry point keeps its signature */
+#define DA_ABI_VERSION 2
 
 enum da_status {
   DA_OK = 0,

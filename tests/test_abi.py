@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), name
     # the Python binding covers the header exactly
     assert sorted(_capi.SIGNATURES) == declared
-    assert lib.da_abi_version() == 1
+    assert lib.da_abi_version() == 2
 
 
 def test_no_torch_types_or_cxx_in_header():
