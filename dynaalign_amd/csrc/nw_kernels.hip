@@ -881,6 +881,40 @@ __global__ __launch_bounds__(1024) void k_dd_scan(const int32_t *__restrict__ in
   }
   if (tid == 0) out[n] = (OUT)carry_s;
 }
+// the two flag arrays of the plan (multi-copy / single-copy representatives) scanned in ONE pass of one workgroup: the counts ride in
+// the two halves of a 64-bit word (n < 2^31), so the cost is that of a single scan (0.14 ms at n = 100k, twice that as two launches)
+__global__ __launch_bounds__(1024) void k_dd_scan_pair(const int32_t *__restrict__ fm, const int32_t *__restrict__ fs, int32_t *__restrict__ pm,
+                                                       int32_t *__restrict__ ps, int32_t n) {
+  __shared__ uint64_t wsum[16];
+  __shared__ uint64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int32_t base = 0; base < n; base += 1024) {
+    const int32_t i = base + tid;
+    const uint64_t v = i < n ? ((uint64_t)(uint32_t)fm[i] | ((uint64_t)(uint32_t)fs[i] << 32)) : 0;
+    uint64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint64_t carry = carry_s;
+    if (i < n) {
+      const uint64_t e = carry + woff + x - v;
+      pm[i] = (int32_t)(uint32_t)e;
+      ps[i] = (int32_t)(uint32_t)(e >> 32);
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) { pm[n] = (int32_t)(uint32_t)carry_s; ps[n] = (int32_t)(uint32_t)(carry_s >> 32); }
+}
 __global__ __launch_bounds__(256) void k_dd_assign(const int32_t *__restrict__ rep, const int32_t *__restrict__ mult,
                                                    const int32_t *__restrict__ last, const int32_t *__restrict__ pm,
                                                    const int32_t *__restrict__ ps, const int64_t *__restrict__ off, int32_t n,
@@ -955,8 +989,7 @@ int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t 
   hipLaunchKernelGGL(k_dd_insert, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1);
   hipLaunchKernelGGL(k_dd_lookup, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1, p.rep, p.mult, p.last);
   hipLaunchKernelGGL(k_dd_flags, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, (int32_t)n, p.fm, p.fs);
-  hipLaunchKernelGGL(k_dd_scan<int32_t>, dim3(1), dim3(1024), 0, stream, p.fm, p.pm, (int32_t)n);
-  hipLaunchKernelGGL(k_dd_scan<int32_t>, dim3(1), dim3(1024), 0, stream, p.fs, p.ps, (int32_t)n);
+  hipLaunchKernelGGL(k_dd_scan_pair, dim3(1), dim3(1024), 0, stream, p.fm, p.fs, p.pm, p.ps, (int32_t)n);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
