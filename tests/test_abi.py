@@ -189,3 +189,35 @@ def test_opts_struct_layout_and_rccl_binding(lib):
         assert str(e.value) == "Invalid amino acid in sequence2: J"
     with pytest.raises(ValueError):
         da.similarityMH(["ACDEF"], 4, 50, devices=[0], exchange="ring")
+
+
+def test_duplicate_route_entry_points_reject_bad_arguments(lib):
+    """argument checks of the round-2 device entry points run before anything touches a GPU: NULL pointers, a da_unique_plan whose
+    struct_size is too small, bad ranks / worlds / leading dimensions all come back as DA_ERR_BAD_ARG with a message"""
+    import ctypes
+    from dynaalign_amd import _capi
+    BAD = _capi.DA_ERR_BAD_ARG
+    plan = _capi.DaUniquePlan()
+    plan.struct_size = ctypes.sizeof(_capi.DaUniquePlan)
+    pp = ctypes.addressof(plan)
+    assert lib.da_dev_unique_plan(None, None, 10, 100, None, 0, pp, None) == BAD and b"NULL" in lib.da_last_error()
+    small = _capi.DaUniquePlan()
+    small.struct_size = 8
+    assert lib.da_dev_unique_plan(1, 1, 10, 100, 256, 1 << 30, ctypes.addressof(small), None) == BAD
+    assert lib.da_dev_unique_plan(1, 1, 0, 0, 256, 1 << 30, pp, None) != 0          # empty input: the reference's message
+    assert lib.da_dev_unique_plan_bytes(100000, 2000000) > 4 * 100000 * 10
+    assert lib.da_dev_shards_to_table(None, 0, 100, 2, 9, None, 104, None) == BAD
+    assert lib.da_dev_shards_to_table(1, 0, 100, 0, 9, 1, 104, None) == BAD          # world < 1
+    assert lib.da_dev_shards_to_table(1, 0, 100, 2, 17, 1, 104, None) == BAD         # value_bits > 16
+    assert lib.da_dev_expand_unique(1, 8, 1, pp, 0, 500, 0, None, 0, 1, 8, None) == BAD    # plan without device pointers
+    plan.n, plan.unique, plan.d_uidx, plan.d_ufirst = 100, 40, 1, 1
+    assert lib.da_dev_expand_unique(None, 40, 1, pp, 0, 500, 0, None, 0, 1, 100, None) == BAD
+    assert lib.da_dev_expand_unique(1, 8, 1, pp, 0, 500, 0, None, 0, 1, 100, None) == BAD  # ld_table < unique
+    assert lib.da_dev_expand_unique(1, 40, 0, pp, 0, 500, 0, None, 0, 1, 100, None) == BAD # table_world < 1
+    assert lib.da_dev_nw_unique_rows(pp, 20, 0, 10, 4, 0, 1, 1, 40, None) == BAD           # plan lacks strings / block bounds
+    assert lib.da_dev_unique_rows(None, 40, pp, None, None) == BAD
+    assert lib.da_dev_upper_histogram_rows(1, 8, 1, 100, 501, 1, None) == BAD              # ld < n
+    assert lib.da_dev_extract_edges_rows(1, 100, None, 100, 1, 501, 1, 1, 1, 1, 10, 1, None) == BAD
+    assert lib.da_dev_expand_workspace_bytes(100000, 45000, 0, 500, 0) == 45000 * 100000 * 2
+    assert lib.da_dev_expand_workspace_bytes(100000, 70000, 0, 500, 0) == 256              # > 65536 unique strings: no fast passes
+    assert lib.da_dev_unique_rows_bytes(100001, 10) == 10 * 100008 * 2
