@@ -451,6 +451,14 @@ def test_100k_headline_workload_properties(da):
     ratio = torch.from_numpy(np.arange(n_hash + 1, dtype=np.float64) / n_hash).cuda()   # host IEEE divide
     for r0 in range(0, n, 5000):                                   # f64 matrix == counts / n_hash everywhere
         assert torch.equal(out[r0:r0 + 5000], ratio[cnt[r0:r0 + 5000].long()])
+    # the one-call route bench.py times (duplicates collapsed: K1 / K1b / K2 on the 44 931 unique strings + index expansion)
+    # must reproduce the whole 80 GB matrix bit for bit
+    out.fill_(-1.0)
+    device.similarity_mh(ds, 4, n_hash, seeds, out=out)
+    route = device.mh_last_route()
+    assert route["dedup"] and route["unique"] == len(set(seqs))
+    for r0 in range(0, n, 5000):
+        assert torch.equal(out[r0:r0 + 5000], ratio[cnt[r0:r0 + 5000].long()])
     del cnt
     # NW on the same set: sampled rows against the oracle, symmetry, diagonal
     assert int(device.nw_encode(ds).item()) == 0
