@@ -215,8 +215,11 @@ double modularity_of(const Graph &g, const std::vector<int32_t> &comm, double re
 // -- scanning a vertex's adjacency and summing the edge weights per neighbouring community (2 900 entries per vertex at
 // N = 100k, thresh_p = .8) -- only depends on the communities of the vertex's NEIGHBOURS.  After the first pass few vertices
 // move (3 371, 2 064, ... of 100 000), so helper threads run those scans AHEAD of the deciding thread (a window of positions in
-// the visiting order) and the deciding thread uses a scan iff no neighbour of the vertex has moved since the scan started
-// (it stamps the neighbours of every vertex it moves with a move counter); otherwise it scans itself.  A scan is the same
+// the visiting order) and the deciding thread uses a scan iff no neighbour of the vertex has moved since the scan started;
+// otherwise it scans itself.  Two ways to know: in a pass with few moves the decider stamps the neighbours of every vertex it
+// moves with a move counter (2 900 writes per move, a compare per use); in a pass where most vertices move (the first) that
+// would cost as much as the scans, so it keeps a log of the moved vertices instead, lets the helpers run only a few positions
+// ahead and looks the handful of moves made since a scan up in the vertex's sorted adjacency (binary searches).  A scan is the same
 // canonical-order sum whoever runs it, so the membership is bit-identical to the one-thread run whatever the timing; when most
 // scans of a pass turn out stale (the first pass: everything moves) the helpers are parked for the rest of the pass.
 struct Scan {                       // neighbouring communities of one vertex in order of first appearance + weight to each
@@ -277,11 +280,21 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
   const bool debug = getenv("DYNAALIGN_LOUVAIN_DEBUG") != nullptr;
   const int nthreads = host_threads((int64_t)g.adj.size());
   const int nhelp = nthreads - 1;
-  constexpr int32_t WINDOW = 512, WINDOW_MIN = 32;            // positions of the visiting order the helpers may run ahead: the ring /
+  constexpr int32_t WINDOW = 512, WINDOW_MIN = 32, WINDOW_MIN_LOG = 4;             // positions of the visiting order the helpers may run ahead: the ring /
   std::atomic<int32_t> window(WINDOW_MIN);                    // what the decider currently allows (few moves -> far ahead; many -> close)
   std::vector<Scan> ring(nhelp > 0 ? (size_t)WINDOW : 1);
   std::vector<std::atomic<uint8_t>> state(nhelp > 0 ? (size_t)n : 0);   // per position: 0 free, 1 helper scanning, 2 helper done, 3 decider's own
-  std::vector<uint64_t> stamp(nhelp > 0 ? (size_t)n : 0, 0);  // per vertex: move counter when a neighbour last moved (decider only)
+  std::vector<uint64_t> stamp(nhelp > 0 ? (size_t)n : 0, 0);  // per vertex: move counter when a neighbour last moved (decider only; stamp mode)
+  constexpr uint64_t MOVE_LOG = 4096;                         // the last MOVE_LOG moved vertices, move e at slot e % MOVE_LOG (decider only)
+  std::vector<int32_t> move_log(nhelp > 0 ? (size_t)MOVE_LOG : 0, -1);
+  // did a neighbour of v move after move number `since`?  (moves since + 1 .. now; adjacency lists are sorted by neighbour id)
+  auto neighbour_moved = [&](int32_t v, uint64_t since, uint64_t now) {
+    if (now - since > MOVE_LOG) return true;                  // the log no longer reaches back that far
+    const int32_t *b = g.adj.data() + g.ptr[(size_t)v], *e = g.adj.data() + g.ptr[(size_t)v + 1];
+    for (uint64_t m = since + 1; m <= now; ++m)
+      if (std::binary_search(b, e, move_log[(size_t)(m % MOVE_LOG)])) return true;
+    return false;
+  };
   std::atomic<uint64_t> epoch(0);                             // moves so far
   std::atomic<int32_t> decided(0), next_scan(0);              // positions finished by the decider / handed to helpers
   std::atomic<int> phase(0);                                  // 0 parked, 1 scanning, 2 quit
@@ -330,8 +343,12 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
   ScanScratch my_sc((size_t)n);
   Scan my_scan;
   double q_prev = modularity_now();
+  int64_t prev_changed = n;                                     // the first pass moves (nearly) everything
   for (;;) {
+    const bool log_mode = prev_changed * 10 > (int64_t)n;       // many moves expected: move log + close window; few: stamps + far window
+    const int32_t wmin = log_mode ? WINDOW_MIN_LOG : WINDOW_MIN;
     int64_t changed = 0, used = 0, stale = 0, used_blk = 0, stale_blk = 0;
+    uint64_t looked_up_blk = 0;                                 // moves looked up by the validity checks of this block
     const auto t_pass = std::chrono::steady_clock::now();
     bool use_scans = nhelp > 0;
     if (nhelp > 0) {                                          // open the pass for the helpers (none of them is scanning any more)
@@ -339,7 +356,7 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
       for (int32_t i = 0; i < n; ++i) state[(size_t)i].store(0, std::memory_order_relaxed);
       decided.store(0, std::memory_order_relaxed);
       next_scan.store(0, std::memory_order_relaxed);
-      window.store(WINDOW_MIN, std::memory_order_relaxed);
+      window.store(wmin, std::memory_order_relaxed);
       pass_id.fetch_add(1, std::memory_order_acq_rel);
       phase.store(1, std::memory_order_release);
     }
@@ -352,7 +369,9 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
         if (!state[(size_t)idx].compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) {
           while (state[(size_t)idx].load(std::memory_order_acquire) != 2) std::this_thread::yield();    // a helper is finishing it
           const Scan &slot = ring[(size_t)(idx % WINDOW)];
-          if (use_scans && stamp[(size_t)v] <= slot.epoch) { sn = &slot; ++used; ++used_blk; }
+          const uint64_t now = epoch.load(std::memory_order_relaxed);
+          looked_up_blk += now - slot.epoch;
+          if (use_scans && (log_mode ? !neighbour_moved(v, slot.epoch, now) : stamp[(size_t)v] <= slot.epoch)) { sn = &slot; ++used; ++used_blk; }
           else { ++stale; ++stale_blk; }
         }
       }
@@ -379,8 +398,11 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
         in[(size_t)best] += 2.0 * w_best + lv;
         __atomic_store_n(&comm_p[(size_t)v], best, __ATOMIC_RELAXED);
         const uint64_t e = epoch.load(std::memory_order_relaxed) + 1;
-        if (use_scans)                                          // scans of v's neighbours that started before this move are stale
-          for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) stamp[(size_t)g.adj[(size_t)q]] = e;
+        if (nhelp > 0) {                                         // scans of v's neighbours that started before move e are stale
+          if (log_mode) move_log[(size_t)(e % MOVE_LOG)] = v;
+          else if (use_scans)
+            for (int64_t q = g.ptr[(size_t)v]; q < g.ptr[(size_t)v + 1]; ++q) stamp[(size_t)g.adj[(size_t)q]] = e;
+        }
         epoch.store(e, std::memory_order_release);
       }
       if (nhelp > 0) {
@@ -388,10 +410,14 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
         if (use_scans && (idx & 1023) == 1023) {                   // every 1024 positions: how many scans were stale?
           const int32_t w = window.load(std::memory_order_relaxed);
           if (2 * stale_blk > used_blk + stale_blk) {              // most: stay closer behind the decider, or -- already close (the
-            if (w > WINDOW_MIN) window.store(std::max(WINDOW_MIN, w / 4), std::memory_order_relaxed);   // first pass: everything
-            else { phase.store(0, std::memory_order_release); use_scans = false; }   // moves) -- park the helpers and stop stamping
-          } else if (10 * stale_blk < used_blk + stale_blk && w < WINDOW) window.store(w * 2, std::memory_order_relaxed);
+            if (w > wmin) window.store(std::max(wmin, w / 4), std::memory_order_relaxed);   // first pass: everything
+            else { phase.store(0, std::memory_order_release); use_scans = false; }   // moves) -- park the helpers
+          } else if (log_mode && looked_up_blk > 3 * 1024 && w > wmin) {   // every look-up is a binary search in a cold adjacency list: keep
+            window.store(std::max(wmin, w / 2), std::memory_order_relaxed);   // the moves made between a scan and its use to ~2
+          } else if (10 * stale_blk < used_blk + stale_blk && (!log_mode || looked_up_blk < 1024) && w < WINDOW)
+            window.store(w * 2, std::memory_order_relaxed);
           used_blk = stale_blk = 0;
+          looked_up_blk = 0;
         }
       }
     }
@@ -400,6 +426,7 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
       fprintf(stderr, "[louvain] n=%d pass: %lld moved, %.3f s (%d helper threads: %lld scans used, %lld stale)\n", n, (long long)changed,
               std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count(), nhelp, (long long)used, (long long)stale);
     if (debug && nhelp > 0) fprintf(stderr, "   helper scans so far %llu, avg %.2f us\n", (unsigned long long)dbg_cnt.load(), dbg_cnt.load() ? dbg_ns.load() / 1e3 / dbg_cnt.load() : 0.0);
+    prev_changed = changed;
     if (changed == 0) break;
     *moved = true;
     const double q_now = modularity_now();
