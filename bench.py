@@ -384,7 +384,21 @@ def main():
                               "phases_ms": dph, "roofline": k2_roofline(dph["k2_ms"], state["bits"]),
                               "note": "DYNAALIGN_MH_NO_DEDUP=1: every row goes through K1 / K1b / K2"}
             state["bits"] = route["plane_bits"]
+    def same_as_single_gpu(compute_ref):
+        """N > 1 only, outside every timed region: this rank recomputes the whole matrix by itself (single-GPU call) and compares
+        it with what the sharded step left in `out`, bit for bit; the ranks' verdicts are AND-ed.  Makes the first run of the RCCL
+        path on real hardware self-checking."""
+        ref = torch.empty((n, n), dtype=torch.float64, device="cuda")
+        compute_ref(ref)
+        torch.cuda.synchronize()
+        ok = all(torch.equal(out[r0:r0 + 5000].view(torch.int64), ref[r0:r0 + 5000].view(torch.int64)) for r0 in range(0, n, 5000))
+        del ref
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     if world > 1:
+        line["verified_against_single_gpu"] = same_as_single_gpu(lambda ref: device.similarity_mh(ds, k, n_hash, d_seeds, out=ref))
         line["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                         "all_gather_bytes_per_rank": int(state["block_bytes"]), "all_gather_ms": phases["all_gather"],
                         "finalize_ms": phases["shards_to_table"] + phases["expand"] if state["dedup"] else phases["finalize"]}
@@ -418,6 +432,8 @@ def main():
                   "gcups": cells / t_nw / 1e9}
         if world > 1:
             nw_obj["route"] = {"n": n, "unique": nw_unique, "dedup": nw_dedup}
+            nw_obj["verified_against_single_gpu"] = same_as_single_gpu(
+                lambda ref: device.nw(ds, "BLOSUM62", 10, 4, 0, n, True, _capi.DA_OUT_F64, out=ref))
         if world == 1:
             # the call collapses byte-identical sequences first (exact): the DP runs on the table of unique strings as an
             # ordered square and the N x N result is an index expansion (da_nw_last_route: unique count + phase times)
