@@ -388,14 +388,22 @@ def main():
         """N > 1 only, outside every timed region: this rank recomputes the whole matrix by itself (single-GPU call) and compares
         it with what the sharded step left in `out`, bit for bit; the ranks' verdicts are AND-ed.  Makes the first run of the RCCL
         path on real hardware self-checking."""
-        ref = torch.empty((n, n), dtype=torch.float64, device="cuda")
-        compute_ref(ref)
-        torch.cuda.synchronize()
-        ok = all(torch.equal(out[r0:r0 + 5000].view(torch.int64), ref[r0:r0 + 5000].view(torch.int64)) for r0 in range(0, n, 5000))
-        del ref
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(t.item())
+        try:
+            torch.cuda.empty_cache()
+            ref = torch.empty((n, n), dtype=torch.float64, device="cuda")
+            compute_ref(ref)
+            torch.cuda.synchronize()
+            ok = 1 if all(torch.equal(out[r0:r0 + 5000].view(torch.int64), ref[r0:r0 + 5000].view(torch.int64))
+                          for r0 in range(0, n, 5000)) else 0
+            del ref
+        except Exception as e:                                  # (e.g. no room for a second matrix): never fail the measurement over the check
+            print("[bench] rank %d: self-check skipped: %s" % (rank, e), file=sys.stderr)
+            ok = 2
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return None if int(hi.item()) == 2 else bool(lo.item())
 
     if world > 1:
         line["verified_against_single_gpu"] = same_as_single_gpu(lambda ref: device.similarity_mh(ds, k, n_hash, d_seeds, out=ref))
