@@ -48,7 +48,7 @@ namespace {
 // Large device buffers are kept for the next call instead of going back to the driver: hipMalloc / hipFree of the
 // 80 GB result buffer cost up to 3.2 s every other call on MI355X (profiles/r02_b_host_path_trace.txt) -- more than the
 // 1.5 s the PCIe copy of the result takes -- and clusterbreak calls sim_fn again and again.  Per device up to MAX_PARKED
-// buffers of >= 1 MiB totalling at most 45 % of the device's memory are parked (one call of the duplicate-collapsing routes uses four:
+// buffers of >= 1 MiB totalling at most 30 % of the device's memory are parked (one call of the duplicate-collapsing routes uses four:
 // plan, table, gathered table, plane workspace); a request takes the smallest parked buffer that fits it and is at most
 // twice its size (a 300 MB request must not walk away with the 9 GB buffer the next allocation of the same call wants);
 // when room is needed the smallest parked buffers go first (cheapest to allocate again).  da_release_device_memory()
@@ -59,12 +59,12 @@ struct BigCache {
   struct Ent { int dev; void *p; size_t bytes; };
   std::mutex m;
   std::vector<Ent> parked;
-  std::vector<size_t> budget;                                   // per device: 45 % of its memory (0 = not asked yet)
+  std::vector<size_t> budget;                                   // per device: 30 % of its memory (0 = not asked yet)
   size_t budget_of(int dev) {
     if ((size_t)dev >= budget.size()) budget.resize((size_t)dev + 1, 0);
     if (!budget[(size_t)dev]) {
       size_t free_b = 0, total_b = 0;
-      budget[(size_t)dev] = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b / 100 * 45 : (size_t)64 << 30;
+      budget[(size_t)dev] = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b / 100 * 30 : (size_t)64 << 30;
     }
     return budget[(size_t)dev];
   }
