@@ -1466,6 +1466,7 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
   if ((rc = check_offsets(offsets, n, &total, &max_len)) != DA_OK) return rc;
   if ((rc = nw_validate(residues, offsets, n)) != DA_OK) return rc;
   if ((rc = require_device()) != DA_OK) return rc;
+  Trace tr("similarityNW host path");
   DeviceInput in;
   if ((rc = in.upload(residues, offsets, n, total, nullptr, 0)) != DA_OK) return rc;
   DevBuf codes, bad;
@@ -1481,8 +1482,15 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
     // as for similarityMH: the (matches << 8 | length) codes cross PCIe and the host divides (src/pairwiseSeqAlign.cpp:311)
     DevBuf dcode;
     if ((rc = dcode.alloc((size_t)n * (size_t)n * sizeof(uint16_t))) != DA_OK) return rc;
+    tr.mark("validation + upload + allocations");
     if ((rc = nw_full_symmetric(codes.as<uint8_t>(), in.off.as<int64_t>(), n, total, max_len, mid, gap_open, gap_ext, DA_OUT_COMPACT,
                                 dcode.p, n, nullptr)) != DA_OK) return rc;
+    if (tr.on) {
+      const NwRoute &r = nw_route();
+      fprintf(stderr, "[dynaalign]   (plan %.2f ms, DP %.2f ms, expansion %.2f ms; %lld unique of %lld)\n", r.plan_ms, r.dp_ms, r.expand_ms,
+                (long long)r.unique, (long long)r.n);
+    }
+    tr.mark("codes on the device (uint16)");
     std::vector<double> table(65536);
     const uint64_t nan_bits = 0xFFF8000000000000ULL;        // 0/0 as the reference's x86 host produces it
     for (uint32_t v = 0; v < 65536; ++v) {
@@ -1490,7 +1498,9 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
       if (ln == 0) memcpy(&table[v], &nan_bits, 8);
       else table[v] = (double)(v >> 8) / (double)ln;
     }
-    return d2h_pipelined(out_f64, dcode.p, (size_t)n * (size_t)n * sizeof(uint16_t), table.data());
+    rc = d2h_pipelined(out_f64, dcode.p, (size_t)n * (size_t)n * sizeof(uint16_t), table.data());
+    tr.mark("device -> host + widen");
+    return rc;
   }
   if (out_f64) {
     const int64_t blk = rows_per_block(n, sizeof(double));
