@@ -10,14 +10,14 @@ the hot path in the package: without the HIP library and a GPU every compute
 call raises.
 """
 from ._capi import DynaAlignError, load as load_library  # noqa: F401
-from .clusterbreak import clusterbreak, louvain, netcluster  # noqa: F401
+from .clusterbreak import clusterbreak, louvain, louvain_csr, netcluster  # noqa: F401
 from .similarity import (  # noqa: F401
     SimilarityMatrix, get_option, hash_family_seeds, mh_counts, minhash_signatures, nw_pairs,
     pack_sequences, quantile_type7, set_option, similarityMH, similarityMH_edges, similarityNW, similarityNW_edges,
 )
 
 __all__ = [
-    "clusterbreak", "netcluster", "louvain",
+    "clusterbreak", "netcluster", "louvain", "louvain_csr",
     "similarityMH", "similarityNW", "similarityMH_edges", "similarityNW_edges", "quantile_type7", "minhash_signatures", "mh_counts", "nw_pairs", "hash_family_seeds",
     "pack_sequences", "set_option", "get_option", "SimilarityMatrix", "DynaAlignError", "load_library",
 ]

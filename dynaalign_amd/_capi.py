@@ -71,6 +71,9 @@ SIGNATURES = {
     "da_dev_shard_histogram": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "da_dev_shard_extract_edges": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "da_louvain": (_i32, [_i64, _i64, _vp, _vp, _vp, C.c_double, _u32, _vp, _vp, _vp]),
+    "da_louvain_csr": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, C.c_double, _u32, _vp, _vp, _vp]),
+    "da_dev_edges_to_csr_bytes": (_sz, [_i64, _i64]),
+    "da_dev_edges_to_csr": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "da_matrix_id": (_i32, [C.c_char_p]),
     "da_shard_rows": (_i64, [_i64, _i32, _i32]),
     "da_shard_ld": (_i64, [_i64, _i32, _i32]),

@@ -55,6 +55,26 @@ def louvain(n, ei, ej, ew, resolution=1.05, seed=0, weights=True, return_modular
     return (member, float(q[0])) if return_modularity else member
 
 
+def louvain_csr(n, ptr, adj, codes, loop_codes, values, resolution=1.05, seed=0, weights=True, return_modularity=False):
+    """`louvain` on a graph that is already canonical (da_louvain_csr): symmetric CSR, weights as uint16 codes into `values`,
+    self-loops per vertex as codes (0xFFFF = none).  What MinHashSession.edges_csr hands over -- sorted on the device, no host-side
+    sort of the edge list.  weights=False clusters the unweighted graph (every code stands for 1.0).  Same result as `louvain`
+    on the corresponding edge list."""
+    lib = _capi.load()
+    ptr = np.ascontiguousarray(ptr, np.int64)
+    adj = np.ascontiguousarray(adj, np.int32)
+    codes = np.ascontiguousarray(codes, np.uint16)
+    loop_codes = np.ascontiguousarray(loop_codes, np.uint16)
+    values = np.ascontiguousarray(values, np.float64) if weights else np.ones(len(values), np.float64)
+    member = np.zeros(max(int(n), 1), np.int32)
+    q = np.zeros(1, np.float64)
+    lv = np.zeros(1, np.int32)
+    _capi.check(lib.da_louvain_csr(int(n), ptr.ctypes.data, adj.ctypes.data, codes.ctypes.data, loop_codes.ctypes.data, values.ctypes.data,
+                                   len(values), float(resolution), int(seed) & 0xFFFFFFFF, member.ctypes.data, q.ctypes.data, lv.ctypes.data))
+    member = member[:int(n)]
+    return (member, float(q[0])) if return_modularity else member
+
+
 def _quantile_type7_sorted_parts(x, p):
     """stats::quantile(x, p, type = 7) for one probability, R's own arithmetic (quantile.default):
     index = 1 + (n - 1) p; lo = floor, hi = ceiling; qs = x[lo]; if index > lo and x[hi] != qs:
@@ -146,6 +166,8 @@ def clusterbreak(pep, thresh_p=0.8, size_max=10, size_min=3, max_itr=10000, sim_
     if sim_fn is None and session is None:
         from .similarity import similarityMH
         sim_fn = lambda x: similarityMH(x, k=2, n_hash=50)                               # noqa: E731  (:185)
+    import os
+    csr_path = session is not None and cluster_fn is None and not os.environ.get("DYNAALIGN_CLUSTERBREAK_NO_CSR")
     cluster_fn = cluster_fn or louvain
     out_seq, out_lab, filtered = [], [], []                                              # state$out.df, state$filter.df
     state = {"itr": 1, "convergence": 1}                                                 # :199-200
@@ -170,10 +192,20 @@ def clusterbreak(pep, thresh_p=0.8, size_max=10, size_min=3, max_itr=10000, sim_
             return
         itr = state["itr"]
         t0 = time.perf_counter()
-        thr, ei, ej, ew = level_edges(idx)
-        t1 = time.perf_counter()
         m = len(idx)
-        c_index = _run_cluster_fn(cluster_fn, m, ei, ej, ew, cluster_wt, (int(cluster_seed) + itr) & 0xFFFFFFFF)   # :222
+        seed_c = (int(cluster_seed) + itr) & 0xFFFFFFFF
+        if csr_path and m >= 2:
+            # device edge path + built-in Louvain: the graph arrives as canonical CSR sorted on the device (same graph, same result)
+            thr, n_edges, ptr, adj, codes, loops, values = session.edges_csr(idx, thresh_p)
+            t1 = time.perf_counter()
+            c_index = louvain_csr(m, ptr, adj, codes, loops, values, seed=seed_c, weights=bool(cluster_wt)).astype(np.int64)   # :222
+            del ptr, adj, codes, loops
+        else:
+            thr, ei, ej, ew = level_edges(idx)
+            n_edges = len(ei)
+            t1 = time.perf_counter()
+            c_index = _run_cluster_fn(cluster_fn, m, ei, ej, ew, cluster_wt, seed_c)     # :222
+            del ei, ej, ew
         t2 = time.perf_counter()
         c_size = np.bincount(c_index, minlength=1)[1:] if m else np.zeros(0, np.int64)   # tabulate(c.index)   :224
         ids = np.arange(1, len(c_size) + 1)
@@ -190,10 +222,10 @@ def clusterbreak(pep, thresh_p=0.8, size_max=10, size_min=3, max_itr=10000, sim_
         for t in np.nonzero(keep)[0]:                                                    # :233-236 / :239-243
             out_seq.append(pep[idx[t]])
             out_lab.append("%d.%d" % (itr, c_index[t]))
-        levels.append({"itr": itr, "n": m, "threshold": thr, "edges": int(len(ei)), "clusters": int(len(c_size)),
+        levels.append({"itr": itr, "n": m, "threshold": thr, "edges": int(n_edges), "clusters": int(len(c_size)),
                        "oversize": int(len(id_itr)), "similarity_s": t1 - t0, "cluster_s": t2 - t1})
         log_message("call %d: n=%d threshold=%g edges=%d clusters=%d oversize=%d (similarity %.3f s, clustering %.3f s)"
-                    % (itr, m, thr, len(ei), len(c_size), len(id_itr), t1 - t0, t2 - t1))
+                    % (itr, m, thr, n_edges, len(c_size), len(id_itr), t1 - t0, t2 - t1))
         if len(id_itr) == 0:
             return
         # :246-254 -- oversize clusters in order of first appearance (unique(pep.new[,2])), each a new call

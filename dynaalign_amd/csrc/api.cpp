@@ -981,6 +981,19 @@ int da_dev_extract_edges(const uint16_t *d_compact, int64_t ld, int64_t n, const
                               reinterpret_cast<unsigned long long *>(d_count), static_cast<hipStream_t>(stream));
 }
 
+// the device edge list (da_dev_extract_edges[_rows]: i <= j, codes) as the symmetric CSR da_louvain_csr clusters -- sorted on the
+// device (one radix sort of 2 m keys), so the host neither sorts 1.45e8 edges nor carries 16 bytes per edge
+size_t da_dev_edges_to_csr_bytes(int64_t n_edges, int64_t n) { return edges_to_csr_workspace_bytes(n_edges, n); }
+
+int da_dev_edges_to_csr(const int32_t *d_i, const int32_t *d_j, const uint16_t *d_v, int64_t n_edges, int64_t n, void *d_work,
+                        size_t work_bytes, int64_t *d_ptr, int32_t *d_adj, uint16_t *d_codes, uint16_t *d_loops, void *stream) {
+  if (n <= 0) return fail(DA_ERR_EMPTY_INPUT, "%s", da_status_message(DA_ERR_EMPTY_INPUT));
+  if (n_edges < 0 || !d_ptr || !d_loops || (n_edges > 0 && (!d_i || !d_j || !d_v || !d_adj || !d_codes || !d_work)))
+    return fail(DA_ERR_BAD_ARG, "bad edges -> CSR arguments");
+  if (n_edges > 0 && (reinterpret_cast<uintptr_t>(d_work) & 255)) return fail(DA_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+  return launch_edges_to_csr(d_i, d_j, d_v, n_edges, n, d_work, work_bytes, d_ptr, d_adj, d_codes, d_loops, static_cast<hipStream_t>(stream));
+}
+
 // R's quantile(x, p, type = 7) (stats::quantile.default, the default the reference's
 // R/clusterbreak.R:219 uses) of the multiset {values[b] x hist[b]}, values ascending:
 //   index = 1 + (N-1) p; lo = floor(index); hi = ceiling(index); q = x[lo];

@@ -171,6 +171,10 @@ int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8
 int launch_gather_columns(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, const int32_t *d_ufirst, int64_t n, int64_t U,
                           uint16_t *d_F, int64_t ld_f, bool from_first_tile, hipStream_t stream, int table_world = 1,
                           int64_t table_rows_local = 0);
+// graph_kernels.hip: (i <= j, code) edge list -> symmetric CSR sorted by (row, column); diagonal entries -> loops[] (0xFFFF = none)
+size_t edges_to_csr_workspace_bytes(int64_t m, int64_t n);
+int launch_edges_to_csr(const int32_t *d_i, const int32_t *d_j, const uint16_t *d_v, int64_t m, int64_t n, void *d_work, size_t work_bytes,
+                        int64_t *d_ptr, int32_t *d_adj, uint16_t *d_codes, uint16_t *d_loops, hipStream_t stream);
 int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream);
 int launch_acc_counts(uint32_t *d_acc, const uint16_t *d_cnt, int64_t count, bool first, hipStream_t stream);
 int launch_counts32_to_f64(const uint32_t *d_acc, double *d_out, int64_t count, int n_hash, hipStream_t stream);

@@ -12,6 +12,8 @@
 
 #include <algorithm>
 
+#include <hipcub/hipcub.hpp>
+
 namespace da {
 namespace {
 
@@ -188,7 +190,81 @@ __global__ __launch_bounds__(G_THREADS) void k_extract_edges(const uint16_t *__r
     }
 }
 
+// ---- edge list -> symmetric CSR on the device (the graph the caller's Louvain step wants; da_louvain_csr) -------------------
+// (i, j, code) with i <= j  ->  both directions of every off-diagonal edge as 64-bit keys row << 32 | col (diagonal entries go to
+// loops[] and get the sentinel row n), one radix sort of the pairs, row pointers by binary search, columns = low key halves.
+__global__ __launch_bounds__(256) void k_edges_to_keys(const int32_t *__restrict__ ei, const int32_t *__restrict__ ej,
+                                                       const uint16_t *__restrict__ ev, int64_t m, int64_t n, uint64_t *__restrict__ keys,
+                                                       uint16_t *__restrict__ vals, uint16_t *__restrict__ loops) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= m) return;
+  const uint32_t i = (uint32_t)ei[e], j = (uint32_t)ej[e];
+  const uint16_t v = ev[e];
+  if (i == j) {
+    loops[i] = v;
+    keys[2 * e] = keys[2 * e + 1] = (uint64_t)n << 32;
+    vals[2 * e] = vals[2 * e + 1] = 0;
+  } else {
+    keys[2 * e] = ((uint64_t)i << 32) | j;
+    keys[2 * e + 1] = ((uint64_t)j << 32) | i;
+    vals[2 * e] = vals[2 * e + 1] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_csr_ptr(const uint64_t *__restrict__ keys, int64_t count, int64_t n, int64_t *__restrict__ ptr) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v > n) return;
+  const uint64_t want = (uint64_t)v << 32;                    // first key of row v (v = n: the sentinel = number of real entries)
+  int64_t lo = 0, hi = count;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  ptr[v] = lo;
+}
+__global__ __launch_bounds__(256) void k_csr_cols(const uint64_t *__restrict__ keys, const int64_t *__restrict__ ptr, int64_t n,
+                                                  int32_t *__restrict__ adj) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < ptr[n]) adj[k] = (int32_t)(uint32_t)keys[k];
+}
+
 }  // namespace
+
+static int key_bits(int64_t n) {
+  int b = 0;
+  for (int64_t t = n; t > 0; t >>= 1) ++b;
+  return 32 + b;
+}
+// workspace: keys in / out (2 x 2m x 8 B), values in (2m x 2 B; the sorted values go straight to d_codes) + the sort's own scratch
+size_t edges_to_csr_workspace_bytes(int64_t m, int64_t n) {
+  if (m <= 0) return 256;
+  size_t temp = 0;
+  const int64_t N = 2 * m;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint16_t *)nullptr,
+                                           (uint16_t *)nullptr, N, 0, key_bits(n), nullptr);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  return up((size_t)N * 8) * 2 + up((size_t)N * 2) + up(temp) + 256;
+}
+int launch_edges_to_csr(const int32_t *d_i, const int32_t *d_j, const uint16_t *d_v, int64_t m, int64_t n, void *d_work, size_t work_bytes,
+                        int64_t *d_ptr, int32_t *d_adj, uint16_t *d_codes, uint16_t *d_loops, hipStream_t stream) {
+  if (n <= 0) return DA_OK;
+  if (n > 0x7ffffff0LL || m > (int64_t)1 << 40) return fail(DA_ERR_UNSUPPORTED, "edge list too large");
+  DA_HIP_TRY(hipMemsetAsync(d_loops, 0xff, (size_t)n * 2, stream));
+  if (m <= 0) { DA_HIP_TRY(hipMemsetAsync(d_ptr, 0, (size_t)(n + 1) * 8, stream)); return DA_OK; }
+  if (work_bytes < edges_to_csr_workspace_bytes(m, n)) return fail(DA_ERR_BAD_ARG, "edges -> CSR: workspace too small");
+  const int64_t N = 2 * m;
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  char *w = static_cast<char *>(d_work);
+  uint64_t *keys_in = reinterpret_cast<uint64_t *>(w); w += up((size_t)N * 8);
+  uint64_t *keys_out = reinterpret_cast<uint64_t *>(w); w += up((size_t)N * 8);
+  uint16_t *vals_in = reinterpret_cast<uint16_t *>(w); w += up((size_t)N * 2);
+  size_t temp = work_bytes - (size_t)(w - static_cast<char *>(d_work));
+  hipLaunchKernelGGL(k_edges_to_keys, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, stream, d_i, d_j, d_v, m, n, keys_in, vals_in, d_loops);
+  DA_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w, temp, keys_in, keys_out, vals_in, d_codes, N, 0, key_bits(n), stream));
+  hipLaunchKernelGGL(k_csr_ptr, dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, stream, keys_out, N, n, d_ptr);
+  hipLaunchKernelGGL(k_csr_cols, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream, keys_out, d_ptr, n, d_adj);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
 
 static Layout make_layout(int64_t n, int rank, int world, const int32_t *rowmap = nullptr) {
   Layout lay;

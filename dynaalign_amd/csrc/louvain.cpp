@@ -517,22 +517,9 @@ void aggregate(const Graph &g, const std::vector<int32_t> &comm, int32_t nc, Gra
 
 using namespace da;
 
-extern "C" int da_louvain(int64_t n_vertices, int64_t n_edges, const int32_t *ei, const int32_t *ej, const double *ew,
-                          double resolution, uint32_t seed, int32_t *membership_out, double *modularity_out,
-                          int32_t *levels_out) {
-  if (n_vertices < 0 || n_edges < 0 || n_vertices > 0x7fffffffLL) return fail(DA_ERR_BAD_ARG, "bad vertex / edge count");
-  if (n_vertices > 0 && !membership_out) return fail(DA_ERR_BAD_ARG, "NULL membership buffer");
-  if (n_edges > 0 && (!ei || !ej || !ew)) return fail(DA_ERR_BAD_ARG, "NULL edge arrays");
-  if (!(resolution >= 0.0)) return fail(DA_ERR_BAD_ARG, "resolution must be >= 0");
-  if (modularity_out) *modularity_out = 0.0;
-  if (levels_out) *levels_out = 0;
-  if (n_vertices == 0) return DA_OK;
-  Graph g0;
-  const auto t_start = std::chrono::steady_clock::now();
-  int rc = build_graph(n_vertices, n_edges, ei, ej, ew, g0);
-  if (rc != DA_OK) return rc;
-  if (getenv("DYNAALIGN_LOUVAIN_DEBUG"))
-    fprintf(stderr, "[louvain] graph built in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+// the multilevel loop on a canonical graph (shared by the two entry points)
+static int run_levels(const Graph &g0, int64_t n_vertices, double resolution, uint32_t seed, int32_t *membership_out,
+                      double *modularity_out, int32_t *levels_out) {
   Mt19937 rng(seed);
   std::vector<int32_t> member((size_t)n_vertices);             // community of every ORIGINAL vertex so far
   std::iota(member.begin(), member.end(), 0);
@@ -564,4 +551,80 @@ extern "C" int da_louvain(int64_t n_vertices, int64_t n_edges, const int32_t *ei
   if (levels_out) *levels_out = levels;
   for (int64_t v = 0; v < n_vertices; ++v) membership_out[v] = member[(size_t)v] + 1;
   return DA_OK;
+}
+
+// The same clustering from a graph that is ALREADY canonical: symmetric CSR (both directions of every edge, columns ascending,
+// no duplicates, no diagonal entries), weights given as codes into a value table, loops per vertex (0xFFFF = none) -- what
+// da_dev_edges_to_csr produces on the device from the thresholded similarity (no host-side sort, no 16-byte-per-edge list).
+// Identical result to da_louvain on the corresponding edge list: the graph is the one build_graph would build, entry for entry.
+extern "C" int da_louvain_csr(int64_t n_vertices, const int64_t *ptr, const int32_t *adj, const uint16_t *codes, const uint16_t *loop_codes,
+                              const double *values, int32_t n_values, double resolution, uint32_t seed, int32_t *membership_out,
+                              double *modularity_out, int32_t *levels_out) {
+  if (n_vertices < 0 || n_vertices > 0x7fffffffLL) return fail(DA_ERR_BAD_ARG, "bad vertex count");
+  if (n_vertices > 0 && (!membership_out || !ptr)) return fail(DA_ERR_BAD_ARG, "NULL pointer");
+  if (!(resolution >= 0.0)) return fail(DA_ERR_BAD_ARG, "resolution must be >= 0");
+  if (modularity_out) *modularity_out = 0.0;
+  if (levels_out) *levels_out = 0;
+  if (n_vertices == 0) return DA_OK;
+  const int64_t nnz = ptr[n_vertices];
+  if (ptr[0] != 0 || nnz < 0 || (nnz > 0 && (!adj || !codes)) || !values || n_values <= 0) return fail(DA_ERR_BAD_ARG, "bad CSR arguments");
+  const auto t_start = std::chrono::steady_clock::now();
+  Graph g0;
+  g0.n = (int32_t)n_vertices;
+  g0.ptr.assign(ptr, ptr + n_vertices + 1);
+  g0.adj.resize((size_t)nnz);
+  g0.w.resize((size_t)nnz);
+  g0.loop.assign((size_t)n_vertices, 0.0);
+  for (int64_t v = 0; v < n_vertices; ++v) {
+    if (g0.ptr[(size_t)v + 1] < g0.ptr[(size_t)v]) return fail(DA_ERR_BAD_ARG, "CSR row pointers must not decrease");
+    if (loop_codes && loop_codes[v] != 0xFFFFu) {
+      if ((int32_t)loop_codes[v] >= n_values) return fail(DA_ERR_BAD_ARG, "loop code out of range");
+      g0.loop[(size_t)v] = values[loop_codes[v]];
+    }
+  }
+  std::atomic<int> bad(0);
+  {
+    const int nthreads = host_threads(nnz);
+    run_threads(nthreads, [&](int t) {
+      int64_t v0, v1;
+      volume_range(g0.ptr, n_vertices, t, nthreads, &v0, &v1);
+      for (int64_t v = v0; v < v1; ++v) {
+        int32_t prev = -1;
+        for (int64_t q = g0.ptr[(size_t)v]; q < g0.ptr[(size_t)v + 1]; ++q) {
+          const int32_t a = adj[q];
+          if (a < 0 || a >= n_vertices || a == v || a <= prev || (int32_t)codes[q] >= n_values) { bad.store(1); return; }
+          prev = a;
+          g0.adj[(size_t)q] = a;
+          g0.w[(size_t)q] = values[codes[q]];
+        }
+      }
+    });
+  }
+  if (bad.load()) return fail(DA_ERR_BAD_ARG, "CSR rows must hold ascending, distinct neighbours != the row, codes < n_values");
+  g0.total = 0.0;
+  std::vector<double> k;
+  strengths(g0, k);
+  for (int64_t v = 0; v < n_vertices; ++v) g0.total += k[(size_t)v];
+  if (getenv("DYNAALIGN_LOUVAIN_DEBUG"))
+    fprintf(stderr, "[louvain] graph taken from CSR in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+  return run_levels(g0, n_vertices, resolution, seed, membership_out, modularity_out, levels_out);
+}
+
+extern "C" int da_louvain(int64_t n_vertices, int64_t n_edges, const int32_t *ei, const int32_t *ej, const double *ew,
+                          double resolution, uint32_t seed, int32_t *membership_out, double *modularity_out,
+                          int32_t *levels_out) {
+  if (n_vertices < 0 || n_edges < 0 || n_vertices > 0x7fffffffLL) return fail(DA_ERR_BAD_ARG, "bad vertex / edge count");
+  if (n_vertices > 0 && !membership_out) return fail(DA_ERR_BAD_ARG, "NULL membership buffer");
+  if (n_edges > 0 && (!ei || !ej || !ew)) return fail(DA_ERR_BAD_ARG, "NULL edge arrays");
+  if (!(resolution >= 0.0)) return fail(DA_ERR_BAD_ARG, "resolution must be >= 0");
+  if (modularity_out) *modularity_out = 0.0;
+  if (levels_out) *levels_out = 0;
+  if (n_vertices == 0) return DA_OK;
+  Graph g0;
+  const auto t_start = std::chrono::steady_clock::now();
+  int rc = build_graph(n_vertices, n_edges, ei, ej, ew, g0);
+  if (rc != DA_OK) return rc;
+  if (getenv("DYNAALIGN_LOUVAIN_DEBUG"))
+    fprintf(stderr, "[louvain] graph built in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+  return run_levels(g0, n_vertices, resolution, seed, membership_out, modularity_out, levels_out);
 }

@@ -247,6 +247,24 @@ def extract_edges_rows(rows, plan, keep, capacity, include_diagonal=True):
     return ei, ej, ev, cnt
 
 
+def edges_to_csr(ei, ej, ev, n_edges, n):
+    """(i <= j, code) device edge list -> symmetric CSR on the device (da_dev_edges_to_csr): returns (ptr int64[n+1], adj int32[nnz],
+    codes int16[nnz] (uint16 bit pattern), loops int16[n] (0xFFFF = no self-loop)) as device tensors; nnz = ptr[n]"""
+    lib = _capi.load()
+    dev = ei.device
+    m, n = int(n_edges), int(n)
+    nbytes = int(lib.da_dev_edges_to_csr_bytes(m, n))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    adj = torch.empty(max(2 * m, 1), dtype=torch.int32, device=dev)
+    codes = torch.empty(max(2 * m, 1), dtype=torch.int16, device=dev)
+    loops = torch.empty(max(n, 1), dtype=torch.int16, device=dev)
+    _capi.check(lib.da_dev_edges_to_csr(ei.data_ptr(), ej.data_ptr(), ev.data_ptr(), m, n, work.data_ptr(), nbytes, ptr.data_ptr(),
+                                        adj.data_ptr(), codes.data_ptr(), loops.data_ptr(), _stream()))
+    nnz = int(ptr[n].item())
+    return ptr, adj[:nnz], codes[:nnz], loops[:n]
+
+
 def similarity_mh(ds, k, n_hash, seeds, out=None):
     """similarityMH (src/minHash.cpp:119-188) on a device-resident set, one C call: K1 + K1b + K2, with byte-identical
     sequences collapsed first when that pays (da_dev_similarity_mh).  Returns the (n, n) float64 tensor."""

@@ -409,6 +409,17 @@ int da_dev_shard_extract_edges(const uint16_t *d_local, int64_t ld, int64_t n, i
 int da_louvain(int64_t n_vertices, int64_t n_edges, const int32_t *ei, const int32_t *ej, const double *ew,
                double resolution, uint32_t seed, int32_t *membership_out, double *modularity_out,
                int32_t *levels_out);
+/* The same clustering from a graph that is already canonical: symmetric CSR (both directions of every edge, columns ascending and
+ * distinct, no diagonal entries), weights as codes into values[n_values], self-loops per vertex as codes (0xFFFF = none; NULL = none).
+ * Identical result to da_louvain on the corresponding edge list.  da_dev_edges_to_csr builds exactly this on the device from the
+ * (i <= j, code) list of da_dev_extract_edges[_rows]: d_work = da_dev_edges_to_csr_bytes(n_edges, n) bytes (256-byte aligned),
+ * d_ptr[n + 1], d_adj / d_codes with room for 2 n_edges entries, d_loops[n]; d_ptr[n] = number of entries written. */
+int da_louvain_csr(int64_t n_vertices, const int64_t *ptr, const int32_t *adj, const uint16_t *codes, const uint16_t *loop_codes,
+                   const double *values, int32_t n_values, double resolution, uint32_t seed, int32_t *membership_out,
+                   double *modularity_out, int32_t *levels_out);
+size_t da_dev_edges_to_csr_bytes(int64_t n_edges, int64_t n);
+int da_dev_edges_to_csr(const int32_t *d_i, const int32_t *d_j, const uint16_t *d_v, int64_t n_edges, int64_t n, void *d_work,
+                        size_t work_bytes, int64_t *d_ptr, int32_t *d_adj, uint16_t *d_codes, uint16_t *d_loops, void *stream);
 
 /* name -> id for da_dev_nw; -1 + DA_ERR_BAD_MATRIX message when unknown. */
 int da_matrix_id(const char *matrix_name);

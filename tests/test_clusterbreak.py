@@ -235,3 +235,52 @@ def test_louvain_result_does_not_depend_on_the_thread_count(da, monkeypatch, see
         for rep in range(3):                                    # the helpers' timing differs from run to run
             m, q = da.louvain(n, ei[perm], ej[perm], ew[perm], resolution=1.05, seed=seed, return_modularity=True)
             assert np.array_equal(m, base) and q == q0
+
+
+def _csr_of(n, ei, ej, codes):
+    """numpy construction of what da_dev_edges_to_csr builds: both directions of every off-diagonal edge sorted by (row, col),
+    diagonal entries as loop codes"""
+    off = ei != ej
+    r = np.r_[ei[off], ej[off]].astype(np.int64)
+    c = np.r_[ej[off], ei[off]].astype(np.int64)
+    v = np.r_[codes[off], codes[off]]
+    order = np.lexsort((c, r))
+    r, c, v = r[order], c[order], v[order]
+    ptr = np.zeros(n + 1, np.int64)
+    np.add.at(ptr, r + 1, 1)
+    ptr = np.cumsum(ptr)
+    loops = np.full(n, 0xFFFF, np.uint16)
+    loops[ei[~off]] = codes[~off]
+    return ptr, c.astype(np.int32), v.astype(np.uint16), loops
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("weights", [True, False])
+def test_louvain_csr_equals_louvain_on_the_edge_list(da, seed, weights):
+    """da_louvain_csr (canonical CSR + weight codes, what the device hands over) clusters exactly like da_louvain on the edge list,
+    loops included, weighted and unweighted"""
+    rng = np.random.RandomState(seed)
+    n, levels = 900, 50
+    ei, ej, _ = _planted_graph(rng, n, 9, 0.4, 0.03, levels)
+    codes = rng.randint(1, levels + 1, ei.size).astype(np.uint16)
+    ei = np.r_[ei, np.arange(n, dtype=np.int32)]                 # + every vertex's self-loop (the similarity matrix's diagonal)
+    ej = np.r_[ej, np.arange(n, dtype=np.int32)]
+    codes = np.r_[codes, np.full(n, levels, np.uint16)]
+    values = np.arange(levels + 1, dtype=np.float64) / levels
+    want, qw = da.louvain(n, ei, ej, values[codes], resolution=1.05, seed=seed, weights=weights, return_modularity=True)
+    ptr, adj, cds, loops = _csr_of(n, ei, ej, codes)
+    got, qg = da.louvain_csr(n, ptr, adj, cds, loops, values, resolution=1.05, seed=seed, weights=weights, return_modularity=True)
+    assert np.array_equal(got, want) and qg == qw and len(np.unique(got)) > 1
+
+
+def test_louvain_csr_rejects_a_graph_that_is_not_canonical(da):
+    values = np.array([0.0, 0.5, 1.0])
+    none = np.full(3, 0xFFFF, np.uint16)
+    ok = da.louvain_csr(3, [0, 1, 2, 2], [1, 0], [2, 2], none, values)
+    assert ok.tolist() == [1, 1, 2]
+    for ptr, adj, codes in (([0, 2, 3, 3], [1, 1, 0], [2, 2, 2]),      # duplicate neighbour
+                            ([0, 1, 2, 2], [0, 0], [2, 2]),            # diagonal entry
+                            ([0, 1, 2, 2], [1, 0], [2, 7]),            # code out of range
+                            ([0, 1, 2, 2], [5, 0], [2, 2])):           # neighbour out of range
+        with pytest.raises(da.DynaAlignError):
+            da.louvain_csr(3, ptr, adj, codes, none, values)

@@ -94,3 +94,39 @@ def test_nw_similarity_as_sim_fn(da):
     b = da.clusterbreak(seqs, thresh_p=0.8, size_max=30, size_min=3, sim_fn=sim_oracle, cluster_seed=3)
     assert_same_result(a, b)
     assert a.calls > 3
+
+
+def test_device_csr_equals_the_host_built_graph(da):
+    """da_dev_edges_to_csr (radix sort on the device) against a numpy construction from the same edge list, and the whole
+    recursion with the CSR path against the edge-list path (DYNAALIGN_CLUSTERBREAK_NO_CSR=1): identical labels"""
+    import os
+    import torch
+    from dynaalign_amd import device, synth, _capi
+    from dynaalign_amd.session import MinHashSession
+    n = 3000
+    seqs = synth.to_strings(*synth.h3n2_like(n, 20))
+    sess = MinHashSession(seqs, 4, 200, seed=12345)
+    thr, ei, ej, ew = sess.edges(None, 0.8, sort=False)
+    thr2, n_edges, ptr, adj, codes, loops, values = sess.edges_csr(None, 0.8)
+    assert thr2 == thr and n_edges == len(ei)
+    cd = np.rint(ew * 200).astype(np.uint16)
+    assert np.array_equal(values[cd], ew)
+    off = ei != ej
+    r = np.r_[ei[off], ej[off]].astype(np.int64)
+    c = np.r_[ej[off], ei[off]].astype(np.int64)
+    v = np.r_[cd[off], cd[off]]
+    order = np.lexsort((c, r))
+    want_ptr = np.zeros(n + 1, np.int64)
+    np.add.at(want_ptr, r + 1, 1)
+    assert np.array_equal(ptr, np.cumsum(want_ptr)) and np.array_equal(adj, c[order].astype(np.int32)) and np.array_equal(codes, v[order])
+    want_loops = np.full(n, 0xFFFF, np.uint16)
+    want_loops[ei[~off]] = cd[~off]
+    assert np.array_equal(loops, want_loops)
+    a = da.clusterbreak(seqs, thresh_p=0.8, size_max=200, size_min=3, session=sess, cluster_seed=1)
+    os.environ["DYNAALIGN_CLUSTERBREAK_NO_CSR"] = "1"
+    try:
+        b = da.clusterbreak(seqs, thresh_p=0.8, size_max=200, size_min=3, session=sess, cluster_seed=1)
+    finally:
+        del os.environ["DYNAALIGN_CLUSTERBREAK_NO_CSR"]
+    assert a.calls == b.calls and a.calls > 1
+    assert np.array_equal(a["clustered_seq"], b["clustered_seq"]) and a["filtered_seq"] == b["filtered_seq"]
