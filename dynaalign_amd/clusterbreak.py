@@ -50,7 +50,8 @@ def louvain(n, ei, ej, ew, resolution=1.05, seed=0, weights=True, return_modular
     q = np.zeros(1, np.float64)
     lv = np.zeros(1, np.int32)
     _capi.check(lib.da_louvain(int(n), len(ei), ei.ctypes.data, ej.ctypes.data, ew.ctypes.data, float(resolution),
-                               int(seed) & 0xFFFFFFFF, member.ctypes.data, q.ctypes.data, lv.ctypes.data))
+                               int(seed) & 0xFFFFFFFF, member.ctypes.data, q.ctypes.data if return_modularity else None,   # (the modularity is
+                               lv.ctypes.data))                                                                           # a sweep over all edges)
     member = member[:int(n)]
     return (member, float(q[0])) if return_modularity else member
 
@@ -70,7 +71,8 @@ def louvain_csr(n, ptr, adj, codes, loop_codes, values, resolution=1.05, seed=0,
     q = np.zeros(1, np.float64)
     lv = np.zeros(1, np.int32)
     _capi.check(lib.da_louvain_csr(int(n), ptr.ctypes.data, adj.ctypes.data, codes.ctypes.data, loop_codes.ctypes.data, values.ctypes.data,
-                                   len(values), float(resolution), int(seed) & 0xFFFFFFFF, member.ctypes.data, q.ctypes.data, lv.ctypes.data))
+                                   len(values), float(resolution), int(seed) & 0xFFFFFFFF, member.ctypes.data,
+                                   q.ctypes.data if return_modularity else None, lv.ctypes.data))
     member = member[:int(n)]
     return (member, float(q[0])) if return_modularity else member
 
