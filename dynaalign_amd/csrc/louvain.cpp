@@ -357,8 +357,11 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
   Scan my_scan;
   double q_prev = modularity_now();
   int64_t prev_changed = n;                                     // the first pass moves (nearly) everything
-  for (;;) {
-    const bool log_mode = prev_changed * 10 > (int64_t)n;       // many moves expected: move log + close window; few: stamps + far window
+  for (int pass = 0;; ++pass) {
+    // many moves expected (the first pass of a level; a later pass after one -- other than the first -- that still moved half the
+    // vertices): move log + close window; few (typically everything after the first pass): stamps + far window.  A wrong guess only
+    // costs speed: stale scans are recomputed, mostly-stale passes park the helpers.
+    const bool log_mode = pass == 0 || (pass >= 2 && prev_changed * 2 > (int64_t)n);
     const int32_t wmin = log_mode ? WINDOW_MIN_LOG : WINDOW_MIN;
     int64_t changed = 0, used = 0, stale = 0, used_blk = 0, stale_blk = 0;
     uint64_t looked_up_blk = 0;                                 // moves looked up by the validity checks of this block
