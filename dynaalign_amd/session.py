@@ -52,23 +52,41 @@ class MinHashSession:
         """The thresholded graph of the subset as the canonical symmetric CSR clusterbreak.louvain_csr takes -- sorted ON THE DEVICE
         (da_dev_edges_to_csr), so neither a host-side sort nor 16 bytes per edge: (threshold, n_edges, ptr, adj, codes, loop_codes,
         values) with weight of entry k = values[codes[k]]; n_edges counts i <= j entries like `edges`."""
+        import os, sys, time
+        trace = os.environ.get("DYNAALIGN_TRACE") is not None
+        marks = [("start", time.perf_counter())]
+
+        def mark(what):
+            if trace:
+                torch.cuda.synchronize()
+                marks.append((what, time.perf_counter()))
         planes, m = self.planes(idx)
         if m < 2:
             raise _capi.DynaAlignError(_capi.DA_ERR_BAD_ARG, "the threshold is a quantile of the strict upper triangle: need >= 2 sequences")
+        mark("codes")
         cnt = device.mh_compare(planes, m, self.n_hash, kind=_capi.DA_OUT_COMPACT)
+        mark("compare")
         nbins = self.n_hash + 1
         hist = device.upper_histogram(cnt, m, nbins).cpu().numpy().astype(np.uint64)
         values = np.arange(nbins, dtype=np.float64) / self.n_hash           # src/minHash.cpp:174
         thr = quantile_type7(hist, values, thresh_p)
         keep = (~(values < thr)) & (np.arange(nbins) != 0)
         cap = int(hist[keep].sum()) + m
+        mark("histogram + quantile")
         ei, ej, ev, c = device.extract_edges(cnt, m, keep, cap)
         got = int(c.item())
         assert got == cap, (got, cap)
         del cnt
+        mark("extract")
         ptr, adj, codes, loops = device.edges_to_csr(ei, ej, ev, got, m)
-        return (thr, got, ptr.cpu().numpy(), adj.cpu().numpy(), codes.cpu().numpy().view(np.uint16), loops.cpu().numpy().view(np.uint16),
-                values)
+        mark("edges -> CSR")
+        out = (thr, got, ptr.cpu().numpy(), adj.cpu().numpy(), codes.cpu().numpy().view(np.uint16), loops.cpu().numpy().view(np.uint16),
+               values)
+        mark("device -> host")
+        if trace and m >= 20000:
+            print("[dynaalign] edges_csr m=%d: %s" % (m, ", ".join("%s %.1f ms" % (w, (t - marks[i][1]) * 1e3)
+                                                                    for i, (w, t) in enumerate(marks[1:]))), file=sys.stderr)
+        return out
 
     def edges(self, idx=None, thresh_p=0.8, sort=True):
         """(threshold, i, j, weight) of the subset after clusterbreak's quantile threshold, i <= j positions in idx;
