@@ -72,8 +72,8 @@ from dynaalign_amd import synth
 res, off = getattr(synth, gen)(n, 20)
 seqs = synth.to_strings(res, off)
 t = time.perf_counter()
-if kind == "mh":
-    rc, M = O.similarity_mh(seqs, 4, 500, O.seeds(12345, 500))
+if kind in ("mh", "mh_rowptr"):
+    rc, M = O.similarity_mh(seqs, 4, 500, O.seeds(12345, 500), rowptr=(kind == "mh_rowptr"))
     pairs = n * (n - 1) // 2
 else:
     rc, mt, ln, sc, _ = O.nw_rows(seqs, 0, rows)
@@ -107,26 +107,39 @@ def cpu_leg(kind, n, rows, gen):
 
 def cpu_baseline(gen, target_s):
     """The CPU oracle (kind 'port': the repo's C restatement -- reference loop nest, its two OpenMP
-    sites for MH, serial NW) on a bounded sample of the same workload, in a child process."""
+    sites for MH, serial NW) on a bounded sample of the same workload, in a child process.  `value` is the variant SURVEY 8(d)
+    specifies -- the reference's data structures (row-pointer signature storage, copied k-mers, column-major element stores:
+    orc_similarity_mh_rowptr); the flat-array port is reported beside it."""
     probe = cpu_leg("mh", 1500, 0, gen)
     rate = probe["pairs"] / probe["dt"]
-    ns = int(min(32000, max(2000, (2 * rate * target_s) ** 0.5)))
-    mh = cpu_leg("mh", ns, 0, gen)
+    ns = int(min(32000, max(2000, (rate * target_s) ** 0.5)))   # two MinHash legs share the budget
+    mh_flat = cpu_leg("mh", ns, 0, gen)
+    mh = cpu_leg("mh_rowptr", ns, 0, gen)
     rows = max(20, int(target_s / (4000 * 2.5e-6)))      # ~2.5 us per 20-mer pair on one core
     nw = cpu_leg("nw", 4000, min(rows, 4000), gen)
     return {
         "value": mh["pairs"] / mh["dt"], "unit": "pairs/s", "cores": mh["threads"], "kind": "port",
-        "sample": "CPU oracle (C restatement: reference loop nest + its 2 OpenMP sites) similarityMH k=4 n_hash=500 on the "
+        "variant": "reference-structured (SURVEY 8(d)): vector<vector>-style row pointers, copied k-mers, column-major M(i,j) stores, -O2 -fopenmp",
+        "sample": "CPU oracle (C restatement: reference loop nest + its 2 OpenMP sites, reference data structures) similarityMH k=4 n_hash=500 on the "
                   "first %d peptides of the same generator, whole call incl. the f64 matrix fill: %.1f s" % (ns, mh["dt"]),
+        "flat_port": {"value": mh_flat["pairs"] / mh_flat["dt"], "unit": "pairs/s", "cores": mh_flat["threads"],
+                      "sample": "the same call on flat arrays (orc_similarity_mh), same %d peptides: %.1f s" % (ns, mh_flat["dt"])},
         "nw": {"value": nw["pairs"] / nw["dt"], "unit": "pairs/s", "cores": 1,
                "sample": "CPU oracle similarityNW BLOSUM62/10/4, %d rows x 4000 peptides, 1 thread (the reference's NW loop "
                          "is serial): %.1f s" % (min(rows, 4000), nw["dt"])},
     }
 
 
+def kernel_source_hash():
+    """identifies the build a profile was taken on: sha256 over the kernel sources (tools/source_hash.py; the GPU box has no .git)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import source_hash
+    return source_hash.source_hash()
+
+
 def pmc_kernel(kernel, n):
     """per-launch counter averages of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*pmc*.json)
-    taken at the same N, + the file they come from"""
+    taken at the same N, + the file they come from and the source hash of the build they were measured on"""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -137,7 +150,7 @@ def pmc_kernel(kernel, n):
                 continue
             k = d.get("kernels", {}).get(kernel)
             if k and d.get("n") == n:
-                best = dict(k, source="profiles/" + f)
+                best = dict(k, source="profiles/" + f, source_hash=d.get("source_hash"))
     return best
 
 
@@ -146,7 +159,11 @@ def pmc_traffic(kernel, n):
     MI355X_MICROARCH.md)"""
     k = pmc_kernel(kernel, n)
     if k and "WRITE_SIZE" in k and "FETCH_SIZE" in k:
-        return {"bytes": (k["WRITE_SIZE"] + 2.0 * k["FETCH_SIZE"]) * 1024.0, "source": k["source"]}
+        cur = kernel_source_hash()
+        src = "%s (kernel sources %s)" % (k["source"], k.get("source_hash") or "unrecorded")
+        if k.get("source_hash") != cur:      # measured on other kernels than the ones running now: not this build's traffic
+            return {"bytes": None, "source": src + " -- STALE: the running sources are %s, traffic not reported" % cur}
+        return {"bytes": (k["WRITE_SIZE"] + 2.0 * k["FETCH_SIZE"]) * 1024.0, "source": src}
     return None
 
 
@@ -302,14 +319,18 @@ def main():
         off-diagonal 128 x 128 tile it reads 128 x 128 uint16 counts once and writes the tile twice as float64 (direct + mirrored)"""
         Tf = wl_n // 128
         tiles = Tf * (Tf - 1) // 2
-        bytes_x = tiles * 128 * 128 * (2 + 16)
+        pairs_x = tiles * 128 * 128                      # unordered pairs this launch finishes (interior off-diagonal tiles)
+        bytes_alg = pairs_x * survey_bytes_per_pair(wl_n)     # SURVEY 8(d): 16.08 B per unordered pair at N = 100k
+        bytes_x = pairs_x * (2 + 16)                     # what the kernel itself moves: 2 B of the gathered table read + 16 B written
         t = rows_ms * 1e-3
         traffic = pmc_traffic("k_expand_rows<false>", wl_n)
-        return {"kernel": "k_expand_rows<false>", "bound": "hbm", "achieved": bytes_x / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": bytes_x / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
+        return {"kernel": "k_expand_rows<false>", "bound": "hbm", "achieved": bytes_alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_alg / t / 1e9 / HBM_PEAK_GBS, "frac_kernel_bytes": bytes_x / t / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None, "avg_launch_ms": rows_ms,
-                "algorithmic_bytes_per_launch": bytes_x,
-                "note": "index expansion of the U x U count table to the dense f64 N x N: 2 B read + 16 B written per unordered pair"}
+                "algorithmic_bytes_per_launch": bytes_alg, "kernel_bytes_per_launch": bytes_x, "pairs_per_launch": pairs_x,
+                "note": "index expansion of the U x U count table to the dense f64 N x N; frac = SURVEY 8(d)'s algorithmic bytes per unordered pair "
+                        "x the pairs of one launch / its HIP-event duration; frac_kernel_bytes counts the kernel's own 2 B read + 16 B written per pair"}
 
     def k2_roofline(k2_ms, plane_bits, wl_n=n, out_elem=8):
         """roofline object of the compare kernel: algorithmic bytes (with the plane words actually read) /
@@ -333,14 +354,22 @@ def main():
         else:
             k2_name = "k_mh_compare<%s, true, %d>" % (f64s, 16 if plane_bits in (14, 15) else plane_bits)
         traffic = pmc_traffic(k2_name, wl_n) if world == 1 else None
-        return {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_k2 / k2 / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,
+        # SURVEY 8(d)'s figure for one launch: all unordered pairs x 16.08 B (float64 result); for the uint16 kinds 8(d) says to
+        # count N^2 x 2 for the result -- that is the kernel's own figure, used for both
+        bytes_alg = (wl_n * (wl_n - 1) / 2) * survey_bytes_per_pair(wl_n) if (world == 1 and out_elem == 8) else bytes_k2
+        return {"kernel": k2_name if world == 1 else "k_mh_compare", "bound": "hbm", "achieved": bytes_alg / k2 / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_alg / k2 / 1e9 / HBM_PEAK_GBS,
+                "frac_kernel_bytes": bytes_k2 / k2 / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
-                "avg_launch_ms": k2 * 1e3, "algorithmic_bytes_per_launch": bytes_k2, "plane_bits": plane_bits,
+                "avg_launch_ms": k2 * 1e3, "algorithmic_bytes_per_launch": bytes_alg, "kernel_bytes_per_launch": bytes_k2, "plane_bits": plane_bits,
                 "valu": {"note": "the unit that actually binds: bit-sliced compare = 1 v_bitop3 per pair per bit plane; "
                                  "peak = isolated v_bitop3 issue rate measured on this chip",
                          "lane_ops_per_launch": lane_ops, "achieved_lane_ops_per_s": lane_ops / k2,
                          "peak_lane_ops_per_s": BITOP3_PEAK, "frac": lane_ops / k2 / BITOP3_PEAK}}
+
+    def survey_bytes_per_pair(wl_n):
+        """(N L + 2 x N n_hash 4 + N^2 8) bytes per call / N (N - 1) / 2 unordered pairs"""
+        return (wl_n * L + 2 * wl_n * n_hash * 4 + wl_n * wl_n * 8) / (wl_n * (wl_n - 1) / 2)
 
     k2_key = "k2_ms" if world == 1 else "k2_compare_shard"
     if world > 1 and state.get("dedup"):
@@ -352,6 +381,10 @@ def main():
         main_roof["k2_on_unique"] = k2_roofline(phases["k2_ms"], state["bits"], route["unique"], 2)
     else:
         main_roof = k2_roofline(phases[k2_key], state["bits"])
+    # the whole step against the roofline: SURVEY 8(d)'s bytes of ONE call (8.04e10 at N = 100k) / the step's wall time
+    step_bytes = n * L + 2 * n * n_hash * 4 + n * n * 8
+    main_roof["step_frac"] = step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    main_roof["step_algorithmic_bytes"] = step_bytes
     line = {
         "metric": "sequence-pairs/sec (MinHash k=4 n_hash=500; NW BLOSUM62) at 1/2/4/8 MI355X",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -380,8 +413,10 @@ def main():
                 del os.environ["DYNAALIGN_MH_NO_DEDUP"]
             dsteps = max(2, min(a.steps, 3))
             dph = phase_means(devs)
+            droof = k2_roofline(dph["k2_ms"], state["bits"])
+            droof["step_frac"] = step_bytes / (ddt / dsteps) / 1e9 / HBM_PEAK_GBS
             line["direct"] = {"ms_per_step": ddt / dsteps * 1e3, "value": pairs_mh / (ddt / dsteps), "unit": "pairs/s", "steps": dsteps,
-                              "phases_ms": dph, "roofline": k2_roofline(dph["k2_ms"], state["bits"]),
+                              "phases_ms": dph, "roofline": droof,
                               "note": "DYNAALIGN_MH_NO_DEDUP=1: every row goes through K1 / K1b / K2"}
             state["bits"] = route["plane_bits"]
     def same_as_single_gpu(compute_ref):
@@ -410,6 +445,16 @@ def main():
         line["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                         "all_gather_bytes_per_rank": int(state["block_bytes"]), "all_gather_ms": phases["all_gather"],
                         "finalize_ms": phases["shards_to_table"] + phases["expand"] if state["dedup"] else phases["finalize"]}
+        # the two T_g boundaries SURVEY 8(d) / 8(e) distinguish: (a) the COMPACT matrix complete on every rank (all-gather done [+ the
+        # unique strings' table rebuilt]: what an edge-list / compact consumer needs), (b) + finalize to the dense float64 matrix
+        compact_keys = [k_ for k_ in phase_names if k_ not in ("expand", "finalize")]
+        t_compact = sum(phases[k_] for k_ in compact_keys)
+        t_full = sum(phases[k_] for k_ in phase_names)
+        line["boundaries"] = {
+            "t_g_compact_ms": t_compact, "t_g_compact_pairs_per_s": pairs_mh / (t_compact * 1e-3),
+            "t_g_f64_ms": t_full, "t_g_f64_pairs_per_s": pairs_mh / (t_full * 1e-3),
+            "note": "per-step HIP-event sums on this rank (rank 0); `value` is T_g with the float64 finalize, from the barrier-bracketed "
+                    "wall clock (max over ranks); compact = " + " + ".join(compact_keys)}
         line["route"] = {"n": n, "unique": state["unique"], "dedup": state["dedup"],
                          "note": "dedup: every rank builds the same duplicate plan, the ranks shard the count table of the unique strings "
                                  "(one all-gather of (U/n)^2 of the bytes) and expand it locally; direct: the n x n pair space is sharded"}
@@ -543,10 +588,12 @@ def main():
         usteps = max(2, min(a.steps, 3))
         udt, uevs = timed_steps(lambda: step(uds), usteps, 1)
         uph = phase_means(uevs)
+        uroof = k2_roofline(uph["k2_ms"], state["bits"])
+        uroof["step_frac"] = step_bytes / (udt / usteps) / 1e9 / HBM_PEAK_GBS
         line["uniform"] = {"workload": "similarityMH k=4 n_hash=500 on %d uniform 20-mers (SURVEY 8(d) S100k), dense f64 NxN in HBM" % n,
                            "value": pairs_mh / (udt / usteps), "unit": "pairs/s", "ms_per_step": udt / usteps * 1e3, "steps": usteps,
                            "plane_bits": state["bits"], "phases_ms": uph, "route": {"unique": uevs[-1]["unique"], "dedup": uevs[-1]["dedup"]},
-                           "roofline": k2_roofline(uph["k2_ms"], state["bits"])}
+                           "roofline": uroof}
         del uds
 
     # ---- BASELINE configs[4]: clusterbreak(size_max=800, thresh_p=.8) end to end, GPU similarityMH backend on the
@@ -616,6 +663,24 @@ def main():
             _capi.check(lib.da_similarity_nw(hres.ctypes.data, hoff.ctypes.data, nh, b"BLOSUM62", 10, 4, hout.ctypes.data))
             t_nwh = time.perf_counter() - t0
             th["nw"] = {"s": t_nwh, "value": nh * (nh + 1) // 2 / t_nwh, "unit": "pairs/s", "effective_GBs": nh * nh * 8 / t_nwh / 1e9}
+        # small calls: what clusterbreak's default sim_fn (and the R glue) pays per recursion level on a small subset -- the
+        # fixed cost of one host-pointer call (upload, kernels, one plain copy of the codes, inline widening)
+        small = {}
+        for ns in (16, 256, 2000):
+            sres, soff = getattr(synth, gen_name)(ns, L)
+            sout = np.empty((ns, ns), np.float64)
+            lat = {}
+            for nm, call in (("mh", lambda: lib.da_similarity_mh(sres.ctypes.data, soff.ctypes.data, ns, k, n_hash, seeds.ctypes.data, sout.ctypes.data)),
+                             ("nw", lambda: lib.da_similarity_nw(sres.ctypes.data, soff.ctypes.data, ns, b"BLOSUM62", 10, 4, sout.ctypes.data))):
+                _capi.check(call())
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    _capi.check(call())
+                    ts.append(time.perf_counter() - t0)
+                lat[nm + "_ms"] = min(ts) * 1e3
+            small[str(ns)] = lat
+        th["small_calls"] = dict(small, note="best of 5 whole host-pointer calls (ms) at n = 16 / 256 / 2000")
         line["t_h"] = th
         del hout
 
@@ -623,7 +688,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu:
         cb = cpu_baseline(gen_name, a.cpu_seconds)
         line["cpu_baseline"] = cb
-        sp = {"boundary": "T_h (whole call, result in host memory) on both sides where t_h was measured, else T_k / whole-call CPU"}
+        sp = {"boundary": "T_h (whole call, result in host memory) on both sides where t_h was measured, else T_k / whole-call CPU",
+              "cpu_variant": "cpu_baseline.value = the reference-structured port (SURVEY 8(d)); cpu_baseline.flat_port is not used here"}
         mh_gpu = line.get("t_h", {}).get("mh", {}).get("value")
         nw_gpu = line.get("t_h", {}).get("nw", {}).get("value")
         sp["mh"] = (mh_gpu or value) / cb["value"]

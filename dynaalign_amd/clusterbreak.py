@@ -38,8 +38,9 @@ __all__ = ["clusterbreak", "netcluster", "louvain", "threshold_edges_dense", "Cl
 
 def louvain(n, ei, ej, ew, resolution=1.05, seed=0, weights=True, return_modularity=False):
     """igraph::cluster_louvain(g, weights = E(g)$weight, resolution)$membership on an edge list (0-based,
-    i == j = self-loop).  weights=False clusters the unweighted graph (netcluster's cluster_weight = FALSE,
-    R/clusterbreak.R:127-129).  Returns int32 ids starting at 1 (R's numbering)."""
+    i == j = self-loop).  weights=False clusters the unweighted graph (a graph built with igraph_weight = FALSE; NOT what
+    netcluster's cluster_weight = FALSE does with the default cluster_func -- see _run_cluster_fn).  Returns int32 ids
+    starting at 1 (R's numbering)."""
     lib = _capi.load()
     ei = np.ascontiguousarray(ei, np.int32)
     ej = np.ascontiguousarray(ej, np.int32)
@@ -121,11 +122,24 @@ def netcluster(pepmat, igraph_mode="upper", igraph_weight=True, cluster_func=Non
     M = np.asarray(pepmat, np.float64)
     if M.ndim != 2 or M.shape[0] != M.shape[1]:
         raise ValueError("Input must be a square pairwise similarity matrix")
-    if igraph_mode != "upper":
-        raise NotImplementedError("only igraph_mode = 'upper' (the reference's default, the one clusterbreak uses)")
     n = M.shape[0]
     i, j = np.triu_indices(n, 0)
-    w = M[i, j]
+    # igraph::graph_from_adjacency_matrix(mode = ...) for the undirected modes (igraph's documentation; igraph itself is not
+    # importable here, so everything but "upper" -- the reference's default and the only mode clusterbreak uses -- is unpinned)
+    if igraph_mode == "upper":
+        w = M[i, j]
+    elif igraph_mode == "lower":
+        w = M[j, i]
+    elif igraph_mode in ("max", "undirected"):
+        w = np.maximum(M[i, j], M[j, i])
+    elif igraph_mode == "min":
+        w = np.minimum(M[i, j], M[j, i])
+    elif igraph_mode == "plus":
+        w = np.where(i == j, M[i, j], M[i, j] + M[j, i])
+    elif igraph_mode == "directed":
+        raise ValueError("igraph_mode = 'directed' builds a directed graph; igraph::cluster_louvain only works with undirected graphs")
+    else:
+        raise ValueError("igraph_mode must be one of 'upper', 'lower', 'max', 'undirected', 'min', 'plus'")
     nz = w != 0.0
     i, j, w = i[nz].astype(np.int32), j[nz].astype(np.int32), w[nz]
     if not igraph_weight:
@@ -134,7 +148,13 @@ def netcluster(pepmat, igraph_mode="upper", igraph_weight=True, cluster_func=Non
 
 
 def _run_cluster_fn(cluster_fn, n, i, j, w, cluster_wt, seed):
-    out = cluster_fn(n, i, j, w, seed=seed, weights=bool(cluster_wt))
+    # netcluster (R/clusterbreak.R:125-129) calls cluster_func(network, weights = E(network)$weight) or cluster_func(network).
+    # For the default cluster_func the second form is NOT unweighted: igraph::cluster_louvain(weights = NULL) takes the graph's
+    # `weight` edge attribute when there is one, and graph_from_adjacency_matrix(weighted = TRUE) always creates it -- so the
+    # built-in Louvain keeps the weights whatever cluster_wt says (an unweighted graph arrives here with w = 1).  A caller's own
+    # cluster_fn sees the flag, as the reference's sees the presence of the `weights` argument.
+    builtin = cluster_fn is louvain
+    out = cluster_fn(n, i, j, w, seed=seed, weights=True if builtin else bool(cluster_wt))
     out = np.asarray(out)
     if out.ndim != 1 or out.size != n or not np.issubdtype(out.dtype, np.number):
         raise ValueError("Wrong clustering output format. Output should be a numeric vector of cluster assignment.")  # :134
@@ -200,7 +220,7 @@ def clusterbreak(pep, thresh_p=0.8, size_max=10, size_min=3, max_itr=10000, sim_
             # device edge path + built-in Louvain: the graph arrives as canonical CSR sorted on the device (same graph, same result)
             thr, n_edges, ptr, adj, codes, loops, values = session.edges_csr(idx, thresh_p)
             t1 = time.perf_counter()
-            c_index = louvain_csr(m, ptr, adj, codes, loops, values, seed=seed_c, weights=bool(cluster_wt)).astype(np.int64)   # :222
+            c_index = louvain_csr(m, ptr, adj, codes, loops, values, seed=seed_c, weights=True).astype(np.int64)   # :222 (built-in: see _run_cluster_fn)
             del ptr, adj, codes, loops
         else:
             thr, ei, ej, ew = level_edges(idx)

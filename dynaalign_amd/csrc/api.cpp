@@ -11,6 +11,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstddef>
+#include <map>
 #include <memory>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,8 @@
 #include <vector>
 
 #include "da_common.hpp"
+
+namespace da { size_t destroy_cached_comms(); }   // defined with the multi-device entry points
 
 namespace da {
 
@@ -63,8 +66,11 @@ struct BigCache {
   size_t budget_of(int dev) {
     if ((size_t)dev >= budget.size()) budget.resize((size_t)dev + 1, 0);
     if (!budget[(size_t)dev]) {
-      size_t free_b = 0, total_b = 0;
-      budget[(size_t)dev] = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b / 100 * 30 : (size_t)64 << 30;
+      size_t total_b = 0;
+      int pct = 30;                                            // DYNAALIGN_BUFFER_CACHE_PCT: share of the device's memory that may stay parked
+      if (const char *e = getenv("DYNAALIGN_BUFFER_CACHE_PCT")) pct = std::max(0, std::min(90, atoi(e)));
+      budget[(size_t)dev] = hipDeviceTotalMem(&total_b, dev) == hipSuccess && total_b ? total_b / 100 * (size_t)pct : (size_t)64 << 30;
+      if (!budget[(size_t)dev]) budget[(size_t)dev] = 1;       // 0 % = park nothing (but do not ask again)
     }
     return budget[(size_t)dev];
   }
@@ -78,6 +84,10 @@ struct BigCache {
     void *p = parked[best].p;
     *cap = parked[best].bytes;
     parked.erase(parked.begin() + (long)best);
+    // a buffer may have been parked by an early return with kernels still in flight on some stream: nothing may still be
+    // touching it when its next owner -- possibly on another stream or thread -- starts writing (the device is idle here in
+    // the normal case: the call that parked it ended with a synchronisation, so this costs microseconds)
+    (void)hipDeviceSynchronize();
     return p;
   }
   void park(int dev, void *p, size_t bytes) {                   // (the caller has made `dev` current)
@@ -263,7 +273,7 @@ void widen_u16_to_f64(double *dst, const uint16_t *src, size_t b, size_t e, cons
 // result of N = 100k took 1.48 s at 54 GB/s; as codes it is 20 GB), and the divide behind every table entry is the same IEEE
 // operation on the host as on the device (src/minHash.cpp:174, src/pairwiseSeqAlign.cpp:311).
 int d2h_pipelined(void *dst, const void *d_src, size_t bytes, const double *table = nullptr) {
-  constexpr size_t CHUNK = (size_t)64 << 20;
+  constexpr size_t CHUNK = (size_t)64 << 20, SMALL = (size_t)8 << 20;   // SMALL: codes of n <= 2048 sequences
   constexpr int RING = 4, MAX_WORKERS = 32;
   int WORKERS = table ? 16 : 8;          // host threads per chunk (first-touch page faults of the destination parallelise)
   if (const char *e = getenv("DYNAALIGN_D2H_THREADS")) WORKERS = std::max(1, std::min(MAX_WORKERS, atoi(e)));
@@ -275,6 +285,14 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes, const double *tabl
   }
   if (bytes <= CHUNK && !table) {
     DA_HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return DA_OK;
+  }
+  if (bytes <= SMALL && table) {
+    // small results (clusterbreak calls sim_fn on thousands of small subsets): ONE plain copy of the codes and an inline
+    // widening -- no pinned ring (4 x 64 MiB of hipHostMalloc), no stream / events, no thread pool per call
+    std::vector<uint16_t> codes(bytes / 2);
+    DA_HIP_TRY(hipMemcpy(codes.data(), d_src, bytes, hipMemcpyDeviceToHost));
+    widen_u16_to_f64(static_cast<double *>(dst), codes.data(), 0, bytes / 2, table);
     return DA_OK;
   }
   if (getenv("DYNAALIGN_PLAIN_D2H") && !table) {
@@ -389,7 +407,10 @@ const char *da_status_message(int status) {
 
 int da_abi_version(void) { return DA_ABI_VERSION; }
 
-size_t da_release_device_memory(void) { return big_cache().release(-1); }
+size_t da_release_device_memory(void) {
+  (void)da::destroy_cached_comms();          // cached RCCL communicators (multi-device entry points) go too
+  return big_cache().release(-1);
+}
 
 int da_device_count(void) {
   int cnt = 0;
@@ -1654,9 +1675,16 @@ struct Multi {
   std::vector<std::string> msg;
   std::vector<std::array<double, PH_COUNT>> ms;
   std::unique_ptr<StatusBarrier> bar;
+  double t_entry = 0.0, comm_setup_ms = 0.0;       // entry of the C call; ncclCommInitAll (first call with this device list)
+  std::unique_lock<std::mutex> comm_use;           // held while this call uses the cached communicators
 };
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// RCCL communicators are kept per device list: ncclCommInitAll costs far more than the exchange it serves, and the glue calls
+// once per recursion level.  One call at a time uses them (comm_use_mutex); da_release_device_memory() destroys them.
+std::map<std::vector<int>, std::vector<ncclComm_t>> &comm_cache() { static auto *c = new std::map<std::vector<int>, std::vector<ncclComm_t>>; return *c; }
+std::mutex &comm_use_mutex() { static std::mutex m; return m; }
 
 // rows rank p copies to the host: contiguous, boundaries on 128-row tiles
 void row_split(int64_t n, int P, int p, int64_t *r0, int64_t *r1) {
@@ -1666,6 +1694,7 @@ void row_split(int64_t n, int P, int p, int64_t *r0, int64_t *r1) {
 }
 
 int parse_opts(const da_opts *o, Multi &m) {
+  m.t_entry = now_ms();                              // phase_ms[5] is the whole call: validation and communicator setup included
   m.P = 1; m.exchange = DA_EXCHANGE_ROWS; m.devs.clear();
   if (o) {
     if (o->struct_size < (uint32_t)offsetof(da_opts, phase_ms)) return fail(DA_ERR_BAD_ARG, "da_opts.struct_size is not set (sizeof(da_opts))");
@@ -1691,18 +1720,27 @@ int parse_opts(const da_opts *o, Multi &m) {
   m.ms.assign(m.P, std::array<double, PH_COUNT>{});
   m.bar.reset(new StatusBarrier(m.P));
   if (m.exchange == DA_EXCHANGE_ALLGATHER) {
+    m.comm_use = std::unique_lock<std::mutex>(comm_use_mutex());
     std::lock_guard<std::mutex> g(rccl_mutex());
-    if (!rccl().load()) return fail(DA_ERR_UNSUPPORTED, "DA_EXCHANGE_ALLGATHER needs RCCL: %s", rccl().why.c_str());
-    m.comms.assign(m.P, nullptr);
-    const ncclResult_t r = rccl().CommInitAll(m.comms.data(), m.P, m.devs.data());
-    if (r != ncclSuccess) { m.comms.clear(); return fail(DA_ERR_HIP, "ncclCommInitAll failed: %s", rccl().GetErrorString(r)); }
+    if (!rccl().load()) { m.comm_use.unlock(); return fail(DA_ERR_UNSUPPORTED, "DA_EXCHANGE_ALLGATHER needs RCCL: %s", rccl().why.c_str()); }
+    auto it = comm_cache().find(m.devs);
+    if (it == comm_cache().end()) {
+      const double t0 = now_ms();
+      std::vector<ncclComm_t> comms((size_t)m.P, nullptr);
+      const ncclResult_t r = rccl().CommInitAll(comms.data(), m.P, m.devs.data());
+      if (r != ncclSuccess) { m.comm_use.unlock(); return fail(DA_ERR_HIP, "ncclCommInitAll failed: %s", rccl().GetErrorString(r)); }
+      m.comm_setup_ms = now_ms() - t0;
+      it = comm_cache().emplace(m.devs, std::move(comms)).first;
+    }
+    m.comms = it->second;
   }
   return DA_OK;
 }
 
+// the communicators stay cached (destroy_cached_comms); the call only gives up its right to use them
 void destroy_comms(Multi &m) {
-  for (auto c : m.comms) if (c) (void)rccl().CommDestroy(c);
   m.comms.clear();
+  if (m.comm_use.owns_lock()) m.comm_use.unlock();
 }
 
 // direct xGMI reads of the peers' blocks (PEERCOPY); without it hipMemcpyPeer stages through the host
@@ -1719,7 +1757,7 @@ void enable_peer_access(const Multi &m, int p) {
 
 // run body(p) on one host thread per rank; the first failing rank's status / message become the caller's
 template <typename F> int run_ranks(Multi &m, const da_opts *o, F body) {
-  const double t0 = now_ms();
+  const double t0 = m.t_entry > 0.0 ? m.t_entry : now_ms();
   auto one = [&](int p) {
     int rc = DA_OK;
     if (hipSetDevice(m.devs[p]) != hipSuccess) rc = fail(DA_ERR_HIP, "hipSetDevice(%d) failed", m.devs[p]);
@@ -1744,6 +1782,7 @@ template <typename F> int run_ranks(Multi &m, const da_opts *o, F body) {
       for (int p = 0; p < m.P; ++p) mx = std::max(mx, m.ms[p][k]);
       o->phase_ms[k] = mx;
     }
+    o->phase_ms[PH_SETUP] += m.comm_setup_ms;          // ncclCommInitAll, paid by the first call with this device list
     o->phase_ms[PH_TOTAL] = now_ms() - t0;
   }
   for (int p = 0; p < m.P; ++p)
@@ -1770,6 +1809,16 @@ int exchange_blocks(Multi &m, int p, const void *mine, size_t bytes, void *gathe
 }
 
 }  // namespace
+
+size_t destroy_cached_comms() {
+  std::lock_guard<std::mutex> u(comm_use_mutex());
+  std::lock_guard<std::mutex> g(rccl_mutex());
+  size_t k = 0;
+  for (auto &e : comm_cache())
+    for (auto c : e.second) if (c) { (void)rccl().CommDestroy(c); ++k; }
+  comm_cache().clear();
+  return k;
+}
 }  // namespace da
 
 extern "C" {

@@ -115,7 +115,13 @@ def _alloc_out(rows, n, kind, device, out):
     if out is not None:
         return out
     dt = torch.float64 if kind == DA_OUT_F64 else torch.int16  # int16 holds the uint16 bit pattern
-    return torch.empty((max(rows, 1), max(n, 1)), dtype=dt, device=device)
+    try:
+        return torch.empty((max(rows, 1), max(n, 1)), dtype=dt, device=device)
+    except torch.OutOfMemoryError:
+        # buffers the library parked for its next call are invisible to torch's allocator: hand them back and try once more
+        torch.cuda.empty_cache()
+        _capi.load().da_release_device_memory()
+        return torch.empty((max(rows, 1), max(n, 1)), dtype=dt, device=device)
 
 
 def mh_compare(planes, n, n_hash, row_begin=0, row_end=None, symmetric=None, kind=DA_OUT_F64, out=None):

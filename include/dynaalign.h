@@ -74,8 +74,11 @@ const char *da_last_error(void);
 const char *da_status_message(int status); /* static text for a code ("" if none) */
 int da_abi_version(void);
 int da_device_count(void); /* 0 when no HIP device is usable */
-/* The host-pointer entry points park their large device buffers (>= 256 MiB, at most two per device: the 80 GB
- * result buffer costs seconds to allocate) for the next call; this returns them to the driver.  Returns the bytes freed. */
+/* The library parks its large device buffers (>= 1 MiB; per device at most 16 buffers totalling at most 30 % of the device's
+ * memory (DYNAALIGN_BUFFER_CACHE_PCT changes the share) -- the 80 GB result buffer costs seconds to allocate, and one call of the duplicate-collapsing routes uses four
+ * large buffers) for the next call instead of returning them to the driver.  Parked memory is invisible to other allocators
+ * in the process (e.g. PyTorch's): this call hands everything back.  An allocation of the library's own that would
+ * otherwise fail releases the parked buffers first.  Returns the bytes freed. */
 size_t da_release_device_memory(void);
 
 /* ---- HashFamily (reference src/minHash.cpp:67-89) ------------------------ */
@@ -105,7 +108,8 @@ int da_similarity_mh(const uint8_t *residues, const int64_t *offsets, int64_t n,
  *                          (xGMI is point-to-point: all links at once; no RCCL needed).
  * NW with an exchange needs sequences of <= 64 residues (uint16 shard codes); ROWS has the limits of da_similarity_nw.
  * phase_ms (optional, DA_PHASE_COUNT doubles): per phase the maximum over devices, in ms --
- *   [0] upload + signatures/codes  [1] compare / NW  [2] exchange  [3] finalize  [4] device-to-host  [5] whole call.
+ *   [0] upload + signatures/codes (+ ncclCommInitAll on the first call with a device list: the communicators are cached until
+ *   da_release_device_memory())  [1] compare / NW  [2] exchange  [3] finalize  [4] device-to-host  [5] whole call, from entry.
  * The R glue builds this struct from options(DynaAlign.devices = , DynaAlign.exchange = ) (r_glue/). */
 enum da_exchange { DA_EXCHANGE_ROWS = 0, DA_EXCHANGE_ALLGATHER = 1, DA_EXCHANGE_PEERCOPY = 2 };
 #define DA_PHASE_COUNT 6

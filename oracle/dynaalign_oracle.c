@@ -171,6 +171,77 @@ int orc_similarity_mh(const uint8_t *residues, const int64_t *offsets, int64_t n
   return ORC_OK;
 }
 
+/* The same call with the reference's DATA STRUCTURES (what SURVEY.md 8(d) names as the CPU baseline; bench.py times it):
+ *   - signatures[n][n_hash] as n separately allocated rows behind a row-pointer array (std::vector<std::vector<uint32_t>>,
+ *     src/minHash.cpp:140),
+ *   - per sequence, every k-mer COPIED out of the sequence first (generate_kmers builds a std::vector<std::string>,
+ *     src/minHash.cpp:92-105), then the k-mer-outer / hash-inner loop of :151-156 with the bounds-checked HashFamily::hash
+ *     call (:83-88) -- here a function call through the seed table,
+ *   - the result written through a column-major accessor M(i,j) = out[i + j*n]: one of the two stores per pair is
+ *     stride-n (:175-176).
+ * Same two OpenMP sites, same arithmetic, same result bits as orc_similarity_mh. */
+static uint32_t hashfamily_hash(const uint32_t *seeds, int n_hash, const uint8_t *key, size_t len, int idx, int *oob) {
+  if (idx < 0 || idx >= n_hash) { *oob = 1; return 0; }                 /* src/minHash.cpp:84-86 (Rcpp::stop there) */
+  return orc_murmur3_32(key, len, seeds[idx]);
+}
+int orc_similarity_mh_rowptr(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                             int k, int n_hash, const uint32_t *seeds, double *out) {
+  if (n <= 0) return ORC_ERR_EMPTY_INPUT;
+  if (k <= 0) return ORC_ERR_BAD_K;
+  if (n_hash <= 0) return ORC_ERR_BAD_NHASH;
+  uint32_t **sig = (uint32_t **)calloc((size_t)n, sizeof(uint32_t *));
+  if (!sig) return ORC_ERR_NOMEM;
+  int rc = ORC_OK;
+  for (int64_t i = 0; i < n; ++i) {                                       /* :140 */
+    sig[i] = (uint32_t *)malloc((size_t)n_hash * sizeof(uint32_t));
+    if (!sig[i]) { rc = ORC_ERR_NOMEM; break; }
+    for (int h = 0; h < n_hash; ++h) sig[i][h] = UINT32_MAX;
+  }
+  if (rc == ORC_OK) {
+    int oob_any = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < n; ++i) {                                     /* :143-157 */
+      const int64_t len = offsets[i + 1] - offsets[i];
+      const int64_t nk = orc_num_kmers(len, k);
+      uint8_t **kmers = (uint8_t **)malloc((size_t)(nk > 0 ? nk : 1) * sizeof(uint8_t *));
+      for (int64_t p = 0; p < nk; ++p) {                                  /* :99-103: one string per k-mer */
+        kmers[p] = (uint8_t *)malloc((size_t)k + 1);
+        memcpy(kmers[p], residues + offsets[i] + p, (size_t)k);
+        kmers[p][k] = 0;
+      }
+      for (int64_t p = 0; p < nk; ++p)
+        for (int h = 0; h < n_hash; ++h) {
+          int oob = 0;
+          uint32_t v = hashfamily_hash(seeds, n_hash, kmers[p], (size_t)k, h, &oob);
+          if (oob) oob_any = 1;
+          if (v < sig[i][h]) sig[i][h] = v;                               /* :154 */
+        }
+      for (int64_t p = 0; p < nk; ++p) free(kmers[p]);
+      free(kmers);
+    }
+    (void)oob_any;
+    for (int64_t i = 0; i < n; ++i) {                                     /* :160-178 */
+      out[(size_t)i + (size_t)i * (size_t)n] = 1.0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+      for (int64_t j = i + 1; j < n; ++j) {
+        int matches = 0;
+        for (int h = 0; h < n_hash; ++h)
+          if (sig[i][h] == sig[j][h]) ++matches;
+        double s = (double)matches / n_hash;
+        out[(size_t)i + (size_t)j * (size_t)n] = s;                       /* M(i, j), column-major */
+        out[(size_t)j + (size_t)i * (size_t)n] = s;                       /* M(j, i) */
+      }
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) free(sig[i]);
+  free(sig);
+  return rc;
+}
+
 /* ------------------------------------------------------------------ NW */
 
 int orc_matrix_id(const char *name) {

@@ -72,6 +72,11 @@ void orc_mh_counts_rows(const uint32_t *sig, int64_t n, int n_hash,
 int orc_similarity_mh(const uint8_t *residues, const int64_t *offsets, int64_t n,
                       int k, int n_hash, const uint32_t *seeds, double *out);
 
+/* orc_similarity_mh with the reference's data structures (row-pointer signature storage, copied k-mers, column-major
+ * element stores): the CPU baseline SURVEY.md 8(d) specifies.  Same result bits. */
+int orc_similarity_mh_rowptr(const uint8_t *residues, const int64_t *offsets, int64_t n,
+                             int k, int n_hash, const uint32_t *seeds, double *out);
+
 /* -1 if name is not one of the six tables (src/pairwiseSeqAlign.cpp:190-206) */
 int orc_matrix_id(const char *name);
 const signed char *orc_matrix_table(int id); /* 576 scores, row-major */

@@ -46,6 +46,8 @@ def lib():
         L.orc_mh_counts_rows.argtypes = [u32p, C.c_int64, C.c_int, C.c_int64, C.c_int64, u16p]
         L.orc_similarity_mh.restype = C.c_int
         L.orc_similarity_mh.argtypes = [u8p, i64p, C.c_int64, C.c_int, C.c_int, u32p, f64p]
+        L.orc_similarity_mh_rowptr.restype = C.c_int
+        L.orc_similarity_mh_rowptr.argtypes = [u8p, i64p, C.c_int64, C.c_int, C.c_int, u32p, f64p]
         L.orc_matrix_id.restype = C.c_int
         L.orc_matrix_id.argtypes = [C.c_char_p]
         L.orc_aa_index.restype = C.c_int
@@ -104,13 +106,14 @@ def mh_counts(sig, row_begin=0, row_end=None):
     return out
 
 
-def similarity_mh(seqs, k, n_hash, seedvec):
-    """returns (rc, matrix)"""
+def similarity_mh(seqs, k, n_hash, seedvec, rowptr=False):
+    """returns (rc, matrix); rowptr=True: the variant with the reference's data structures (orc_similarity_mh_rowptr)"""
     res, off = pack(seqs)
     n = len(seqs)
     out = np.zeros((max(n, 1), max(n, 1)), np.float64)
     sv = np.ascontiguousarray(seedvec, np.uint32) if len(seedvec) else np.zeros(1, np.uint32)
-    rc = lib().orc_similarity_mh(res, off, n, k, n_hash, sv, out)
+    fn = lib().orc_similarity_mh_rowptr if rowptr else lib().orc_similarity_mh
+    rc = fn(res, off, n, k, n_hash, sv, out)
     return rc, out[:n, :n]
 
 

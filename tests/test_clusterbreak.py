@@ -81,7 +81,7 @@ def test_louvain_edge_cases(da):
     assert da.louvain(4, [], [], []).tolist() == [1, 2, 3, 4]                 # no edges: everyone alone
     assert da.louvain(3, [0, 1, 2], [0, 1, 2], [1.0, 1.0, 1.0]).tolist() == [1, 2, 3]   # loops only
     assert da.louvain(4, [2, 0], [3, 1], [1.0, 1.0]).tolist() == [1, 1, 2, 2]
-    # weights = FALSE (netcluster's cluster_weight = FALSE): the heavy bridge no longer decides
+    # weights = FALSE (an unweighted graph, igraph_weight = FALSE): the heavy bridge no longer decides
     ei, ej = np.array([0, 0, 1, 3, 3, 4, 2], np.int32), np.array([1, 2, 2, 4, 5, 5, 3], np.int32)
     ew = np.array([1, 1, 1, 1, 1, 1, 50.0])
     assert da.louvain(6, ei, ej, ew, weights=False).tolist() == [1, 1, 1, 2, 2, 2]
@@ -284,3 +284,38 @@ def test_louvain_csr_rejects_a_graph_that_is_not_canonical(da):
                             ([0, 1, 2, 2], [5, 0], [2, 2])):           # neighbour out of range
         with pytest.raises(da.DynaAlignError):
             da.louvain_csr(3, ptr, adj, codes, none, values)
+
+
+def test_netcluster_modes_and_what_cluster_weight_false_means(da):
+    """igraph_mode beyond "upper" (igraph's documented undirected modes; unpinned -- igraph is not importable) and the reference's
+    cluster_weight = FALSE (R/clusterbreak.R:127-129): with the default cluster_func igraph::cluster_louvain(weights = NULL)
+    still reads the graph's `weight` attribute, so the built-in Louvain keeps the weights; only igraph_weight = FALSE
+    (an unweighted graph) drops them.  A caller's own cluster_func sees the flag."""
+    from dynaalign_amd.clusterbreak import netcluster
+    n = 6
+    A = np.zeros((n, n))
+    for a, b, w in ((0, 1, 1), (0, 2, 1), (1, 2, 1), (3, 4, 1), (3, 5, 1), (4, 5, 1), (2, 3, 50.0)):
+        A[a, b] = w                                     # upper triangle only
+    weighted = netcluster(A).tolist()
+    assert weighted != [1, 1, 1, 2, 2, 2]              # the heavy bridge decides
+    assert netcluster(A, cluster_weight=False).tolist() == weighted          # default cluster_func: the weight attribute is still used
+    assert netcluster(A, igraph_weight=False).tolist() == [1, 1, 1, 2, 2, 2]   # an unweighted graph
+    seen = {}
+
+    def mine(n_, i, j, w, seed=0, weights=True):
+        seen["weights"] = weights
+        return np.ones(n_, np.int64)
+    netcluster(A, cluster_func=mine, cluster_weight=False)
+    assert seen["weights"] is False
+    # modes: the same graph from the lower triangle, from both (max / min / plus / undirected)
+    assert netcluster(A.T, igraph_mode="lower").tolist() == weighted
+    assert netcluster(A, igraph_mode="lower").tolist() == [1, 2, 3, 4, 5, 6]   # nothing below the diagonal: no edges
+    assert netcluster(A, igraph_mode="max").tolist() == weighted
+    assert netcluster(A + A.T, igraph_mode="undirected").tolist() == weighted
+    assert netcluster(A + A.T, igraph_mode="min").tolist() == weighted
+    assert netcluster(A, igraph_mode="min").tolist() == [1, 2, 3, 4, 5, 6]
+    assert netcluster(A, igraph_mode="plus").tolist() == weighted
+    with pytest.raises(ValueError):
+        netcluster(A, igraph_mode="directed")
+    with pytest.raises(ValueError):
+        netcluster(A, igraph_mode="sideways")

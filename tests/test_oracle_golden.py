@@ -183,3 +183,21 @@ def test_oracle_is_clean_under_asan_ubsan():
     out = subprocess.run([os.path.join(O.ORACLE_DIR, "selftest_asan")], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "oracle selftest: ok" in out.stdout
+
+
+def test_reference_structured_mh_variant_has_the_same_bits():
+    """orc_similarity_mh_rowptr (row-pointer signatures, copied k-mers, column-major element stores: the CPU baseline SURVEY 8(d)
+    names) == the flat port, bit for bit, on ragged input incl. empty / shorter-than-k sequences; same validation order"""
+    rng = np.random.RandomState(5)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    seqs = ["".join(map(chr, alpha[rng.randint(0, 20, rng.randint(0, 30))])) for _ in range(257)]
+    seqs[7] = seqs[6]
+    for k, n_hash in ((4, 500), (2, 50), (7, 33)):
+        sv = O.seeds(12345, n_hash)
+        rc_a, a = O.similarity_mh(seqs, k, n_hash, sv)
+        rc_b, b = O.similarity_mh(seqs, k, n_hash, sv, rowptr=True)
+        assert rc_a == rc_b == 0
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert O.similarity_mh([], 4, 50, O.seeds(1, 50), rowptr=True)[0] == 1
+    assert O.similarity_mh(["AAAA"], 0, 50, O.seeds(1, 50), rowptr=True)[0] == 2
+    assert O.similarity_mh(["AAAA"], 4, 0, np.zeros(0, np.uint32), rowptr=True)[0] == 3

@@ -34,7 +34,13 @@ import json
 n = 100000
 argv = os.environ.get("BENCH_ARGS", "").split()
 if "--n" in argv: n = int(argv[argv.index("--n") + 1])
-json.dump({"n": n, "bench_args": os.environ.get("BENCH_ARGS", ""), "note": "rocprofv3 --pmc, one pass per counter group; "
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tools"))
+try:
+    import source_hash
+    src_hash = source_hash.source_hash()
+except Exception:
+    src_hash = None
+json.dump({"n": n, "source_hash": src_hash, "bench_args": os.environ.get("BENCH_ARGS", ""), "note": "rocprofv3 --pmc, one pass per counter group; "
            "values are per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-counts wide reads 2x on gfx950)",
            "kernels": {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}},
           open(os.path.join(out, "summary.json"), "w"), indent=1)
