@@ -114,6 +114,8 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
                       void *d_out, int64_t ld, hipStream_t stream, int plane_bits = 32, int tile_stride = 1,
                       bool upper_only = false, int fold_q = 0, int64_t fold_w = 0);
+// frees the idle scratch instances of the role-split compare kernel (da_release_device_memory); returns the bytes freed
+size_t release_compare_scratch();
 // dict_kernels.hip: signatures -> compare operand.  Dictionary codes (8 / 12 / 16 planes per group,
 // whatever the largest column dictionary needs) are exact for n <= DA_DICT_MAX_N; *d_status_out
 // points at two ints in the workspace ({error, largest id count}), valid once the stream has drained.

@@ -78,3 +78,22 @@ def test_committed_14_15_bit_includes_are_the_generators_output(tmp_path, bits):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
                           stdout=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p%d.inc" % bits)).read()
+
+
+@pytest.mark.parametrize("ntiles,ns,tx,ty", [(1, 16, 0, 0), (3, 16, 5, 11), (4, 8, 15, 15), (3, 4, 7, 8), (2, 16, 9, 3)])
+def test_inloop_store_block_over_a_tile_sequence(ntiles, ns, tx, ty):
+    """the block of k_mh_compare_q12 (round 3): counters as before; the PREVIOUS tile's 64 float64 stores issued from inside the stage
+    loop carry the right addresses and values (direct + mirrored, 16 / ns pieces per stage); and the counted vmcnt waits hold in
+    an in-order model of loads and stores (a stage is never read before its three DMA pieces have retired)"""
+    import sim_k2_asm
+    issued, bad, bad_stores = sim_k2_asm.run_inloop(tx, ty, seed=ntiles * 100 + ns, ntiles=ntiles, ns=ns)
+    assert issued == ntiles * ns and bad == 0 and bad_stores == 0
+
+
+def test_committed_inloop_include_is_the_generators_output(tmp_path):
+    out = tmp_path / "k2q.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("K2ASM_")}
+    env["K2ASM_INLOOP"] = "1"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
+                          stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p12q.inc")).read()

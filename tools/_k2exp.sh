@@ -1,11 +1,6 @@
-set -e
 cd $GRAFT_REPO_ROOT
 L=$GRAFT_REPO_ROOT/dynaalign_amd/lib
-for wg in 4 3 2; do
-  for v in dyn dynns; do
-    echo "== persistent $v wg_per_cu=$wg"
-    DYNAALIGN_LIB=$L/libdynaalign_hip_$v.so DYNAALIGN_K2_PERSIST=1 DYNAALIGN_K2_WG_PER_CU=$wg timeout -k 10 120 python tools/k2_time.py 100000 h3n2_like 5
-  done
-done
-echo "== one tile per workgroup (default lib)"
-timeout -k 10 120 python tools/k2_time.py 100000 h3n2_like 5
+echo "== q12 full"; timeout -k 10 120 python tools/k2_time.py 100000 h3n2_like 5 2>/dev/null
+echo "== q12 without the global stores"; DYNAALIGN_LIB=$L/libdynaalign_hip_qx1.so timeout -k 10 120 python tools/k2_time.py 100000 h3n2_like 5 2>/dev/null
+echo "== q12 without the table reads"; DYNAALIGN_LIB=$L/libdynaalign_hip_qx2.so timeout -k 10 120 python tools/k2_time.py 100000 h3n2_like 5 2>/dev/null
+echo "== baseline one tile per WG"; DYNAALIGN_K2_NO_INLOOP=1 timeout -k 10 120 python tools/k2_time.py 100000 h3n2_like 5 2>/dev/null

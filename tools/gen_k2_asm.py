@@ -31,6 +31,11 @@ PERSIST = int(os.environ.get("K2ASM_PERSIST", "0"))   # 1: the block of the PERS
 # workgroup = issue stages 0 and 1 here; bit 1: another tile follows = issue ITS stages 0 and 1 during the last two stages
 # and wait for them before leaving), %[nl]:%[nh] the wave's source base of the next tile, %[sp] ring byte offset of stage 0.
 # Always with the SGPR-base DMA form (the tile switch is two s_mov).
+INLOOP = int(os.environ.get("K2ASM_INLOOP", "0"))     # 1: the block of k_mh_compare_q12 (round 3): the persistent block at THREE workgroups
+# per CU (168 VGPRs), which stores the PREVIOUS tile as float64 from inside this tile's stage loop -- 16 pieces of four 16-byte
+# streaming stores (a 2 x 2 block of the lane's 8 x 8 pairs, direct + mirrored), 16 / ns pieces per stage.  See gen_inloop().
+if INLOOP:
+    PERSIST = 1
 if PERSIST:
     SADDR = 1
     REGOUT = 1
@@ -51,7 +56,12 @@ HALF_LAST = PLANES == 15                                            # the last s
 STAGE_BYTES = 256 * SEGS * 16  # 12288 (20480 with the padded 16-plane slots)
 ROW = 16 * SEGS * 16          # byte distance between the lane's rows / columns in LDS: 768 (1280)
 out = []
+NOSTORE = int(os.environ.get("K2ASM_NOSTORE", "0"))   # experiments on the in-loop block: 1 = leave the global stores out, 2 = leave the table reads out
 def e(x):
+    if NOSTORE == 1 and x.startswith("global_store"):
+        return
+    if NOSTORE == 2 and x.startswith("ds_read_b64 v[16"):
+        return
     out.append(x)
     if SAFE and x.startswith("ds_read"):
         out.append("s_waitcnt lgkmcnt(0)")
@@ -268,6 +278,205 @@ def gen_persistent():
     e("9:")
     e("s_mov_b32 m0, s47")
 
+
+def gen_inloop():
+    """k_mh_compare_q12's block.  Same ring / DMA / plane-loop structure as gen_persistent(); differences:
+      * v64..v95 come IN holding the previous tile's 32 packed mismatch counters (flag bit 2) and go OUT holding this tile's;
+        the block parks the old ones in v128..v159 first;
+      * every stage stores kk = 16 / ns PIECES of the previous tile: piece p = the lane's rows 2rp, 2rp+1 x column pair c2
+        (rp = p >> 2, c2 = p & 3): two packed counters (picked with s_set_gpr_idx) -> four match counts -> four table reads
+        (count -> double, the table is in LDS at %[tb]) -> two direct stores (rows 2rp, 2rp+1 at columns 2c2, 2c2+1) and, after two
+        v_swap, two mirrored ones (the transposed tile: rows 2c2, 2c2+1 at columns 2rp, 2rp+1); addresses = a scalar base
+        (tile + piece, s_mul / s_add) + a per-lane 32-bit offset (v119 direct, v127 mirrored);
+      * vmcnt counts loads and stores together and in order, so the wait for a stage's DMA allows exactly the younger operations:
+        the stores of the two previous stages (s53, s54; each 0 or 4 kk) + the three DMA instructions of the stage after
+        (if one was issued) -- an immediate picked by a compare chain; stages 0 / 1 of a later tile wait the same way (the
+        previous block's last two stages issued %[pw] stores each), so the block needs no drain at its end.
+    Extra operands: %[tb] %[nn] %[odl]:%[odh] %[oml]:%[omh] (previous tile: &out[I0][J0], &out[J0][I0]) %[l8] = 8 ld, %[pw], %[kk]."""
+    P, W1, W2, CNT, DO, LOOPC = "s52", "s53", "s54", "s55", "s60", "s61"
+    e("// generated by tools/gen_k2_asm.py (K2ASM_INLOOP=1) -- do not edit")
+    e("s_mov_b32 s47, m0")
+    if PRIO:
+        e("s_setprio %d" % PRIO)
+    e("s_mov_b32 %s, 0" % S_STAGE)
+    e("v_and_b32 v118, 0xfc, v124")
+    e("v_lshlrev_b32 v118, 2, v118")
+    for r in range(8):
+        for c2 in range(4):
+            e("v_mov_b32 v%d, %s" % (128 + 4 * r + c2, mis(r, c2)))     # park the previous tile's counters
+    for r in range(8):
+        for c2 in range(4):
+            e("v_mov_b32 %s, 0" % mis(r, c2))
+    e("s_mov_b32 %s, 0" % P)
+    e("s_mov_b32 %s, %%[pw]" % W1)
+    e("s_mov_b32 %s, %%[pw]" % W2)
+    e("s_mul_i32 %s, %%[wv], 3072" % S_TMP)
+    e("s_add_u32 s46, %[lb], " + S_TMP)
+    e("s_mov_b32 %s, %%[sp]" % S_SLOT)
+    e("s_add_u32 %s, %%[sp], %d" % (S_ISSUE_SLOT, 2 * STAGE_BYTES))
+    wrap_slot(S_ISSUE_SLOT)
+    e("s_mov_b32 s48, %[sl]")
+    e("s_mov_b32 s49, %[sh]")
+    e("s_bitcmp1_b32 %[fl], 0")
+    e("s_cbranch_scc0 10f")
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_SLOT))
+    issue_saddr()
+    e("s_add_u32 %s, %s, %d" % (S_TMP, S_SLOT, STAGE_BYTES))
+    wrap_slot(S_TMP)
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_TMP))
+    issue_saddr()
+    e("s_branch 11f")
+    e("10:")
+    e("s_add_u32 s48, s48, %[st]")
+    e("s_addc_u32 s49, s49, 0")
+    e("s_add_u32 s48, s48, %[st]")
+    e("s_addc_u32 s49, s49, 0")
+    e("11:")
+
+    def piece_a():
+        e("s_lshr_b32 s58, %s, 2" % P)
+        e("s_and_b32 s59, %s, 3" % P)
+        e("s_lshl_b32 %s, s58, 3" % S_TMP)
+        e("s_add_u32 %s, %s, s59" % (S_TMP, S_TMP))             # register index 8 rp + c2
+        for half, (d0, d1) in enumerate(((160, 162), (164, 166))):
+            e("s_set_gpr_idx_on %s, 0x1" % S_TMP)                  # SRC0 relative (clobbers m0: the DMA sets it before every use)
+            e("s_nop 0")
+            e("v_mov_b32 v126, v%d" % (128 + 4 * half))
+            e("s_set_gpr_idx_off")
+            e("v_sub_u32 v126, %[nn], v126")                       # two match counts: low half column 2 c2, high half column 2 c2 + 1
+            e("v_lshlrev_b32 v%d, 3, v126" % d0)
+            e("v_and_b32 v%d, 0x7fff8, v%d" % (d0, d0))
+            e("v_add_u32 v%d, %%[tb], v%d" % (d0, d0))
+            e("v_lshrrev_b32 v%d, 13, v126" % d1)
+            e("v_and_b32 v%d, 0x7fff8, v%d" % (d1, d1))
+            e("v_add_u32 v%d, %%[tb], v%d" % (d1, d1))
+        for d in (160, 162, 164, 166):
+            e("ds_read_b64 v[%d:%d], v%d" % (d, d + 1, d))
+
+    def piece_b():
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshr_b32 s58, %s, 2" % P)                             # rp
+        e("s_and_b32 s59, %s, 3" % P)                              # c2
+        e("s_lshl_b32 %s, %%[l8], 5" % LOOPC)                      # bytes per 32 rows (LOOPC is free here: reloaded below)
+        # direct: &out[I0 + 32 rp][J0 + 32 c2] = od + rp * (32 ld 8) + c2 * 256
+        e("s_mul_i32 %s, s58, %s" % (S_TMP, LOOPC))
+        e("s_lshl_b32 s56, s59, 8")
+        e("s_add_u32 %s, %s, s56" % (S_TMP, S_TMP))
+        e("s_add_u32 s56, %%[odl], %s" % S_TMP)
+        e("s_addc_u32 s57, %[odh], 0")
+        e("global_store_dwordx4 v119, v[160:163], s[56:57] nt")
+        e("s_add_u32 s56, s56, %[l8]")
+        e("s_addc_u32 s57, s57, 0")
+        e("global_store_dwordx4 v119, v[164:167], s[56:57] nt")
+        # mirrored: &out[J0 + 32 c2][I0 + 32 rp] = om + c2 * (32 ld 8) + rp * 256
+        e("s_mul_i32 %s, s59, %s" % (S_TMP, LOOPC))
+        e("s_lshl_b32 s56, s58, 8")
+        e("s_add_u32 %s, %s, s56" % (S_TMP, S_TMP))
+        e("s_add_u32 s56, %%[oml], %s" % S_TMP)
+        e("s_addc_u32 s57, %[omh], 0")
+        e("s_nop 1")                                               # the two stores above have read their data registers
+        e("v_swap_b32 v162, v164")
+        e("v_swap_b32 v163, v165")
+        e("global_store_dwordx4 v127, v[160:163], s[56:57] nt")
+        e("s_add_u32 s56, s56, %[l8]")
+        e("s_addc_u32 s57, s57, 0")
+        e("global_store_dwordx4 v127, v[164:167], s[56:57] nt")
+        e("s_add_u32 %s, %s, 1" % (P, P))
+        e("s_add_u32 %s, %s, 4" % (CNT, CNT))
+        e("s_nop 1")
+
+    e("2:")
+    # ---- wait for this stage's DMA: allowed in flight = stores of the two previous stages + the next stage's DMA (if issued)
+    e("s_add_u32 %s, %s, %s" % (S_TMP, W1, W2))
+    e("s_add_u32 s58, %s, 1" % S_STAGE)
+    e("s_cmp_lt_u32 s58, %[ns]")
+    e("s_cbranch_scc1 20f")
+    e("s_bitcmp1_b32 %[fl], 1")
+    e("s_cbranch_scc0 21f")
+    e("20:")
+    e("s_add_u32 %s, %s, 3" % (S_TMP, S_TMP))
+    e("21:")
+    vals = [11, 3, 7, 8, 0, 4, 19, 16, 35, 32]
+    for v in vals:
+        e("s_cmp_eq_u32 %s, %d" % (S_TMP, v))
+        e("s_cbranch_scc1 %df" % (100 + v))
+    e("s_waitcnt vmcnt(0)")
+    e("s_branch 4f")
+    for v in vals:
+        e("%d:" % (100 + v))
+        e("s_waitcnt vmcnt(%d)" % v)
+        e("s_branch 4f")
+    e("4:")
+    e("s_barrier")
+    e("v_add_u32 v116, %s, v120" % S_SLOT)
+    e("v_add_u32 v117, %s, v121" % S_SLOT)
+    b_read(0, 0, 0)
+    b_read(1, 0, 1)
+    for r in range(8):
+        e("ds_read_b64 %s, v116 offset:%d" % (a(r), r * ROW))
+    # issue stage + 2 (of this tile, or stage 0 / 1 of the next one)
+    e("s_add_u32 %s, %s, 2" % (S_TMP, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_TMP)
+    e("s_cbranch_scc1 30f")
+    e("s_bitcmp1_b32 %[fl], 1")
+    e("s_cbranch_scc0 5f")
+    e("s_cmp_eq_u32 %s, %%[ns]" % S_TMP)
+    e("s_cbranch_scc0 30f")
+    e("s_mov_b32 s48, %[nl]")
+    e("s_mov_b32 s49, %[nh]")
+    e("30:")
+    e("s_add_u32 %s, s46, %s" % (S_M0, S_ISSUE_SLOT))
+    issue_saddr()
+    e("5:")
+    # ---- the previous tile's pieces of this stage: the first one's table reads fly under the popcounts
+    e("s_mov_b32 %s, 0" % CNT)
+    e("s_mov_b32 %s, 0" % DO)
+    e("s_bitcmp1_b32 %[fl], 2")
+    e("s_cbranch_scc0 40f")
+    e("s_cmp_lt_u32 %s, 16" % P)
+    e("s_cbranch_scc0 40f")
+    e("s_mov_b32 %s, 1" % DO)
+    piece_a()
+    e("40:")
+    e("s_cmp_eq_u32 %s, 0" % S_STAGE)
+    e("s_cbranch_scc1 6f")
+    count_group()
+    e("6:")
+    e("s_cmp_eq_u32 %s, 0" % DO)
+    e("s_cbranch_scc1 43f")
+    piece_b()
+    e("s_sub_u32 %s, %%[kk], 1" % LOOPC)
+    e("41:")
+    e("s_cmp_eq_u32 %s, 0" % LOOPC)
+    e("s_cbranch_scc1 43f")
+    e("s_cmp_lt_u32 %s, 16" % P)
+    e("s_cbranch_scc0 43f")
+    e("s_mov_b32 s62, %s" % LOOPC)                                  # piece_b uses LOOPC as scratch
+    piece_a()
+    piece_b()
+    e("s_sub_u32 %s, s62, 1" % LOOPC)
+    e("s_branch 41b")
+    e("43:")
+    cur = 0
+    for k in range(STEPS):
+        cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)
+    assert cur == 0
+    e("s_mov_b32 %s, %s" % (W2, W1))
+    e("s_mov_b32 %s, %s" % (W1, CNT))
+    e("s_add_u32 %s, %s, %d" % (S_SLOT, S_SLOT, STAGE_BYTES))
+    e("s_cmp_lt_u32 %s, %d" % (S_SLOT, 3 * STAGE_BYTES))
+    e("s_cselect_b32 %s, %s, 0" % (S_SLOT, S_SLOT))
+    e("s_add_u32 %s, %s, %d" % (S_ISSUE_SLOT, S_ISSUE_SLOT, STAGE_BYTES))
+    e("s_cmp_lt_u32 %s, %d" % (S_ISSUE_SLOT, 3 * STAGE_BYTES))
+    e("s_cselect_b32 %s, %s, 0" % (S_ISSUE_SLOT, S_ISSUE_SLOT))
+    e("s_add_u32 %s, %s, 1" % (S_STAGE, S_STAGE))
+    e("s_cmp_lt_u32 %s, %%[ns]" % S_STAGE)
+    e("s_cbranch_scc1 2b")
+    count_group()
+    if PRIO or EPRIO:
+        e("s_setprio %d" % EPRIO)
+    e("s_mov_b32 m0, s47")
+
 def gen_16():
     e("// generated by tools/gen_k2_asm.py (K2ASM_PLANES=%d) -- do not edit" % PLANES)
     e("s_mov_b32 s47, m0")
@@ -328,7 +537,9 @@ def gen_16():
     e("s_mov_b32 m0, s47")
 
 
-if PERSIST:
+if INLOOP:
+    gen_inloop()
+elif PERSIST:
     gen_persistent()
 elif PLANES in (14, 15, 16):
     gen_16()

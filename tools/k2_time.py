@@ -32,6 +32,12 @@ def main():
     r = {"lib": os.path.basename(os.environ.get("DYNAALIGN_LIB", "default")), "n": n, "workload": gen, "plane_bits": planes.bits}
     os.environ.pop("DYNAALIGN_K2_NO_ASM", None)
     r["f64_ms"] = t_ms(lambda: device.mh_compare(planes, n, n_hash, 0, n, True, _capi.DA_OUT_F64, out=out), reps)
+    import ctypes
+    lib = _capi.load()
+    if hasattr(lib, "da_debug_k2_roles_stats"):               # role-split kernel: tiles taken / stored / stored by compute workgroups / mailboxes
+        st = (ctypes.c_uint * 4)()
+        lib.da_debug_k2_roles_stats(st)
+        r["roles"] = {"taken": st[0], "stored": st[1], "stored_by_compute_wg": st[2], "mailboxes": st[3]}
     r["u16_ms"] = t_ms(lambda: device.mh_compare(planes, n, n_hash, 0, n, True, _capi.DA_OUT_COMPACT, out=o16), reps)
     if "--check" in sys.argv:
         os.environ["DYNAALIGN_K2_NO_ASM"] = "1"

@@ -42,7 +42,19 @@ def run15(tx=5, ty=11, seed=1, ns=16):
     return run_persistent(tx, ty, seed, ntiles=1, ns=ns, inc=INC_15, planes=15, slot_bytes=80, ring=2)
 
 
-def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, slot_bytes=48, ring=3):
+INC_Q = os.path.join(os.path.dirname(INC), "k2_loop_p12q.inc")
+
+
+def run_inloop(tx=5, ty=11, seed=1, ntiles=3, ns=16, n_hash=None):
+    """The block of k_mh_compare_q12 (K2ASM_INLOOP=1): like run_persistent, plus (1) the previous tile's 64 float64 stores issued from
+    inside the stage loop are checked -- address and data of every one, against the reference counts of the previous tile --
+    and (2) the counted vmcnt waits are checked against an in-order model of the outstanding vector-memory operations: at every
+    stage barrier the three DMA pieces of the stage about to be read must have retired.  Returns (stages issued, wrong counters,
+    wrong or missing stores)."""
+    return run_persistent(tx, ty, seed, ntiles, ns, inc=INC_Q, inloop=True, n_hash=n_hash or 32 * ns)
+
+
+def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, slot_bytes=48, ring=3, inloop=False, n_hash=500):
     """The block of the persistent kernel (K2ASM_PERSIST=1), executed `ntiles` times in a row on one LDS image, the
     way k_mh_compare_p12 calls it: flags first / has-next, ring phase advancing by ns stages per tile, the next tile's
     source handed in.  The DMA is modelled by ADDRESS: the stage image that appears in the ring is the one the running
@@ -52,8 +64,18 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, s
     STAGE = 256 * slot_bytes; LB = 4096; ST = 128 * slot_bytes; TILE_STRIDE = 1 << 24
     pieces = 64 * slot_bytes // 1024
     random.seed(seed)
-    stages = [[bytes(random.getrandbits(8) for _ in range(STAGE)) for _ in range(ns)] for _ in range(ntiles)]
-    lds = bytearray(LB + ring * STAGE)
+    # (in-loop form: sparse plane words, so that the match counts -- and with them the stored values -- vary)
+    rb = (lambda: random.getrandbits(8) if random.random() < 0.02 else 0) if inloop else (lambda: random.getrandbits(8))
+    stages = [[bytes(rb() for _ in range(STAGE)) for _ in range(ns)] for _ in range(ntiles)]
+    TB = LB + ring * STAGE                        # (in-loop form) the count -> double table: entry c = the 8 bytes (c, ~c)
+    lds = bytearray(TB + 8 * 1024)
+    for c in range(1024):
+        lds[TB + 8 * c:TB + 8 * c + 8] = c.to_bytes(4, 'little') + (c ^ 0xffffffff).to_bytes(4, 'little')
+    LD = 100096; OUT = 1 << 40                    # (in-loop form) leading dimension and base address of the result matrix
+    prev_counts = None; prev_tile = None; bad_stores = 0; pw = 0
+    Vkeep = [0] * 256
+    vm = []                                       # outstanding vector-memory operations, oldest first: ('dma', tile, stage, piece) / ('st',)
+    retired = set()                               # ... carried from block to block: a tile's first two stages are issued by the block before
     labels = {}
     for i, l in enumerate(lines):
         m = re.match(r'^(\d+):$', l)
@@ -65,6 +87,16 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, s
         V = [0] * 256; S = {}
         S['lb'] = LB; S['ns'] = ns; S['st'] = ST; S['wv'] = 0
         S['fl'] = (1 if t == 0 else 0) | (2 if t + 1 < ntiles else 0)
+        stores = []; gpr_idx = None
+        if inloop:
+            for r_ in range(64, 96): V[r_] = Vkeep[r_]          # the previous tile's counters come in in v64..v95
+            I0, J0 = (3 + 2 * t) * 128, (40 + 3 * t) * 128      # this tile's position (any interior off-diagonal one)
+            if prev_tile is not None: S['fl'] |= 4
+            pi, pj = prev_tile if prev_tile is not None else (0, 0)
+            od = OUT + (pi * LD + pj) * 8; om = OUT + (pj * LD + pi) * 8
+            S.update(tb=TB, nn=n_hash * 0x10001, odl=od & 0xffffffff, odh=od >> 32, oml=om & 0xffffffff, omh=om >> 32, l8=LD * 8, pw=pw,
+                     kk=16 // ns)
+            V[119] = ((2 * ty) * LD + 2 * tx) * 8; V[127] = ((2 * tx) * LD + 2 * ty) * 8
         S['sp'] = phase * STAGE
         base = (t + 1) * TILE_STRIDE; nbase = (t + 2) * TILE_STRIDE
         S['sl'], S['sh'] = base & 0xffffffff, base >> 32
@@ -102,10 +134,36 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, s
                     num, d = a[0][:-1], a[0][-1]
                     cands = labels[num]
                     pc = min(c for c in cands if c >= pc) if d == 'f' else max(c for c in cands if c < pc)
-            elif op in ('s_nop', 's_waitcnt', 's_barrier', 's_setprio'): pass
-            elif op == 'v_mov_b32': V[vreg(a[0])] = V[vreg(a[1])] if a[1].startswith('v') else int(a[1], 0)
+            elif op == 's_waitcnt':
+                m = re.match(r'vmcnt\((\d+)\)', a[0])
+                if m and inloop:
+                    keep = int(m.group(1))
+                    done, vm = (vm, []) if keep == 0 else (vm[:-keep], vm[-keep:])
+                    retired.update(x for x in done if x[0] == 'dma')
+            elif op == 's_barrier':
+                if inloop:                        # the stage about to be read: all three pieces must have landed
+                    for q in range(pieces):
+                        assert ('dma', t, S.get('s40', 0), q) in retired, "stage %d of tile %d read before its DMA piece %d retired (vmcnt wait too weak)" % (S.get('s40', 0), t, q)
+            elif op in ('s_nop', 's_setprio'): pass
+            elif op == 's_lshr_b32': S[a[0]] = sval(a[1]) >> sval(a[2])
+            elif op == 's_lshl_b32': S[a[0]] = (sval(a[1]) << sval(a[2])) & 0xffffffff
+            elif op == 's_and_b32': S[a[0]] = sval(a[1]) & sval(a[2])
+            elif op == 's_set_gpr_idx_on': gpr_idx = sval(a[0]); S['m0'] = 0xdead0000 | gpr_idx   # (m0 is clobbered)
+            elif op == 's_set_gpr_idx_off': gpr_idx = None
+            elif op == 'v_mov_b32':
+                if a[1].startswith('v'): V[vreg(a[0])] = V[vreg(a[1]) + (gpr_idx or 0)]
+                else: V[vreg(a[0])] = int(a[1], 0)
             elif op == 'v_and_b32': V[vreg(a[0])] = int(a[1], 0) & V[vreg(a[2])]
             elif op == 'v_lshlrev_b32': V[vreg(a[0])] = (V[vreg(a[2])] << int(a[1])) & 0xffffffff
+            elif op == 'v_lshrrev_b32': V[vreg(a[0])] = V[vreg(a[2])] >> int(a[1])
+            elif op == 'v_sub_u32': V[vreg(a[0])] = (sval(a[1]) - V[vreg(a[2])]) & 0xffffffff
+            elif op == 'v_swap_b32': V[vreg(a[0])], V[vreg(a[1])] = V[vreg(a[1])], V[vreg(a[0])]
+            elif op == 'global_store_dwordx4':
+                m = re.match(r's\[(\d+):(\d+)\]', a[2].split()[0])
+                addr = (S['s' + m.group(1)] | (S['s' + m.group(2)] << 32)) + V[vreg(a[0])]
+                b = vpair(a[1])
+                stores.append((addr, tuple(V[b:b + 4])))
+                vm.append(('st',))
             elif op == 'global_load_lds_dwordx4':
                 m = re.match(r's\[(\d+):(\d+)\]', a[1])
                 addr = S['s' + m.group(1)] | (S['s' + m.group(2)] << 32)
@@ -116,14 +174,16 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, s
                     assert rem == 0 and 0 <= slot < ring, "DMA destination outside the ring: %x" % S['m0']
                     lds[LB + slot * STAGE:LB + (slot + 1) * STAGE] = stages[tt][off // ST]
                     issued_total += 1
+                    dma_tag = (tt, off // ST)
                 else:
                     assert addr % TILE_STRIDE % ST == piece * 1024
+                vm.append(('dma', dma_tag[0], dma_tag[1], piece))
                 piece = (piece + 1) % pieces
             elif op == 'v_add_u32':
                 x = sval(a[1]) if not a[1].startswith('v') else V[vreg(a[1])]
                 V[vreg(a[0])] = (x + V[vreg(a[2])]) & 0xffffffff
             elif op == 'ds_read_b64':
-                b = vpair(a[0]); addr = V[vreg(a[1].split()[0])]; off = int(re.search(r'offset:(\d+)', l).group(1))
+                b = vpair(a[0]); addr = V[vreg(a[1].split()[0])]; mo = re.search(r'offset:(\d+)', l); off = int(mo.group(1)) if mo else 0
                 ad = addr + off
                 V[b] = int.from_bytes(lds[ad:ad + 4], 'little'); V[b + 1] = int.from_bytes(lds[ad + 4:ad + 8], 'little')
             elif op == 'v_xor_b32': V[vreg(a[0])] = V[vreg(a[1])] ^ V[vreg(a[2])]
@@ -138,6 +198,7 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, s
                 raise RuntimeError("unhandled instruction: " + l)
         def word(stage, slot, w):
             o = slot * slot_bytes + w * 4; return int.from_bytes(stages[t][stage][o:o + 4], 'little')
+        counts_now = {}
         for r in range(8):
             for c in range(8):
                 arow = r * 16 + ty; bcol = 128 + c * 16 + tx
@@ -148,8 +209,28 @@ def run_persistent(tx=5, ty=11, seed=1, ntiles=3, ns=16, inc=INC_P, planes=12, s
                         dd |= word(st, arow, pl) ^ word(st, bcol, pl ^ 1)
                     mism += bin(dd).count('1')
                 if ((V[64 + 4 * r + c // 2] >> (16 * (c & 1))) & 0xffff) != mism: bad += 1
+                if inloop: counts_now[(r, c)] = mism
+        if inloop:
+            # DMA pieces of the NEXT tile's first stages issued here retire in the next block: carry them over as already retired
+            # only if that block's waits say so -- modelled by handing the outstanding list on
+            want = {}
+            if prev_counts is not None:
+                def tab(c): return (c, c ^ 0xffffffff)
+                pi, pj = prev_tile
+                for rp in range(4):
+                    for c2 in range(4):
+                        m = {(e, f): n_hash - prev_counts[(2 * rp + e, 2 * c2 + f)] for e in (0, 1) for f in (0, 1)}
+                        for e in (0, 1):      # direct rows 32 rp + 2 ty + e, columns 32 c2 + 2 tx, + 1
+                            want[OUT + ((pi + 32 * rp + 2 * ty + e) * LD + pj + 32 * c2 + 2 * tx) * 8] = tab(m[(e, 0)]) + tab(m[(e, 1)])
+                        for f in (0, 1):      # mirrored rows 32 c2 + 2 tx + f, columns 32 rp + 2 ty, + 1
+                            want[OUT + ((pj + 32 * c2 + 2 * tx + f) * LD + pi + 32 * rp + 2 * ty) * 8] = tab(m[(0, f)]) + tab(m[(1, f)])
+            got = dict(stores)
+            bad_stores += sum(1 for k_, v_ in want.items() if got.get(k_) != v_) + sum(1 for k_ in got if k_ not in want) + (len(stores) - len(got))
+            prev_counts, prev_tile = counts_now, (I0, J0)
+            pw = (4 * (16 // ns)) if (S['fl'] & 4) else 0
+            Vkeep = list(V)
         phase = (phase + ns) % ring
-    return issued_total, bad
+    return (issued_total, bad, bad_stores) if inloop else (issued_total, bad)
 
 
 def run(tx=5, ty=11, seed=1, inc=INC):

@@ -10,6 +10,7 @@
 //   5 compute only, 3/CU                6 store only, 1/CU
 //   7 every workgroup computes and issues the previous tile's 64 stores inside the stage loop, 4 per stage
 //   8 every workgroup computes a tile, then issues its 64 stores (what k_mh_compare_p12 does)
+//   9 roles 3 + 1 with the store role at wave priority 3 (the compute role runs at 2)
 //   hipcc --offload-arch=gfx950 -O3 -o corun corun.hip && ./corun [tiles]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 4) void k_corun(Ctl *ctl, char *buf, unsigned 
   switch (mode) {
     case 0: role = 0; break;
     case 1: role = 1; break;
-    case 2: case 4: role = (ticket & 3u) == 3u ? 1 : 0; break;
+    case 2: case 4: case 9: role = (ticket & 3u) == 3u ? 1 : 0; break;
     case 3: role = (ticket & 1u) ? 1 : 0; break;
     case 5: role = (ticket & 3u) == 3u ? 2 : 0; break;
     case 6: role = (ticket & 3u) == 0u ? 1 : 2; break;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256, 4) void k_corun(Ctl *ctl, char *buf, unsigned 
         compute_tile(0, buf);
       }
     } else {
+      if (mode == 9) __builtin_amdgcn_s_setprio(3);   // the store role issues few instructions: let it go first
       for (;;) {
         const unsigned t = take(&ctl->next_store);
         if (t >= n_store) break;
@@ -161,8 +163,8 @@ int main(int argc, char **argv) {
   const double lane_ops = (double)tiles * 16 * 768 * 256, bytes = (double)tiles * CHUNK;
   printf("%d CUs, %u tiles: %.3g lane-v_bitop3 (+ 1/8 as many half-rate count ops), %.1f GB of stores\n", cus, tiles, lane_ops, bytes / 1e9);
   const char *names[] = {"compute only 4/CU", "store only 4/CU", "roles 3+1", "roles 2+2", "roles 3+1 work-conserving", "compute only 3/CU",
-                         "store only 1/CU", "in-loop stores (4 per stage)", "compute then 64 stores"};
-  for (int mode = 0; mode <= 8; ++mode) {
+                         "store only 1/CU", "in-loop stores (4 per stage)", "compute then 64 stores", "roles 3+1, store role at priority 3"};
+  for (int mode = 0; mode <= 9; ++mode) {
     float best = 1e30f;
     std::vector<unsigned> hist(8, 0);
     for (int rep = 0; rep < 3; ++rep) {
