@@ -173,8 +173,10 @@ __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMA
   }
 }
 
+// (experiment switch: the row-ahead residue fetch helped the direct sweep, 466 -> 418 ms, and cost the ordered mode 98 -> 102 ms)
+template <bool ORD> constexpr bool getenv_free_prefetch_off() { return ORD; }
 template <int NMAX, bool CK, bool ORD>
-__global__ __launch_bounds__(K3_THREADS) void k_nw_short(
+__global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short(   // <= 24 residues: keep 4 waves per SIMD (128 VGPRs)
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
     int kind, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
@@ -329,10 +331,27 @@ __global__ __launch_bounds__(K3_THREADS) void k_nw_short(
       const int32_t pay_mask = in_vgpr((1 << CK_S) - 1), pri_clear = in_vgpr(~CK_PRI);
       // Ix[1][c] = max(NEG-goe, NEG-ge), priority 1, payload of row 0 (nothing)
       const int32_t ixf_first = ((CK_NEG - min(goe, ge)) << CK_S2) + (1 << CK_S);
+      // sequence1's residue of the NEXT row is fetched while this row's chain runs (round 3): the row loop used to open with
+      // ds_read_u8 + s_waitcnt lgkmcnt(0) + v_mad before it could issue its 20 table reads -- an LDS round trip per row in
+      // front of everything (and hipcc rotates a plain C++ prefetch back to that shape).  So the read is inline asm, issued a
+      // row ahead; LDS operations return in order and the extra outstanding one only makes the compiler's counted lgkmcnt waits
+      // stricter, never weaker.  The value is wave-uniform: in an SGPR the table-row offset is scalar arithmetic.
+      typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
+      const uint32_t rc_addr = (uint32_t)(uintptr_t)(lds_u8_t *)&rowcodes[lr][0];
+      uint32_t code_v = 0u;
+      constexpr bool PREFETCH = !getenv_free_prefetch_off<ORD>();
+      if (PREFETCH && m > 0) asm volatile("ds_read_u8 %0, %1" : "=v"(code_v) : "v"(rc_addr) : "memory");
       for (int32_t r = 1; r <= m; ++r) {
         // (making this offset opaque to the compiler turns the per-cell v_mad into a v_add but lets it
         // hoist all 20 lookups: 141 VGPRs / 3 waves per SIMD and 15 % slower -- measured, not kept)
-        const uint32_t row_off = (uint32_t)rowcodes[lr][r - 1] * (24u * (uint32_t)sizeof(int32_t));
+        uint32_t row_off;
+        if (PREFETCH) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(code_v) :: "memory");
+          row_off = __builtin_amdgcn_readfirstlane(code_v) * (24u * (uint32_t)sizeof(int32_t));
+          asm volatile("ds_read_u8 %0, %1" : "=v"(code_v) : "v"(rc_addr + (uint32_t)(r < m ? r : r - 1)) : "memory");
+        } else {
+          row_off = (uint32_t)rowcodes[lr][r - 1] * (24u * (uint32_t)sizeof(int32_t));
+        }
         const char *tab_row = tab_bytes + row_off;
         // column 0 of rows r-1 and r (reference :224-229): max(M,Ix,Iy)[r-1][0] = Ix = -go - (r-2)*ge (frame:
         // ge - go) and M = Iy = -inf at (r,0)
