@@ -354,6 +354,7 @@ def main():
         else:
             k2_name = "k_mh_compare<%s, true, %d>" % (f64s, 16 if plane_bits in (14, 15) else plane_bits)
         traffic = pmc_traffic(k2_name, wl_n) if world == 1 else None
+        pmk = pmc_kernel(k2_name, wl_n) if world == 1 else None
         # SURVEY 8(d)'s figure for one launch: all unordered pairs x 16.08 B (float64 result); for the uint16 kinds 8(d) says to
         # count N^2 x 2 for the result -- that is the kernel's own figure, used for both
         bytes_alg = (wl_n * (wl_n - 1) / 2) * survey_bytes_per_pair(wl_n) if (world == 1 and out_elem == 8) else bytes_k2
@@ -365,7 +366,11 @@ def main():
                 "valu": {"note": "the unit that actually binds: bit-sliced compare = 1 v_bitop3 per pair per bit plane; "
                                  "peak = isolated v_bitop3 issue rate measured on this chip",
                          "lane_ops_per_launch": lane_ops, "achieved_lane_ops_per_s": lane_ops / k2,
-                         "peak_lane_ops_per_s": BITOP3_PEAK, "frac": lane_ops / k2 / BITOP3_PEAK}}
+                         "peak_lane_ops_per_s": BITOP3_PEAK, "frac": lane_ops / k2 / BITOP3_PEAK,
+                         # the compare kernels are POWER-limited: with the float64 stores the shader clock drops to ~1.8 GHz (2.2 without;
+                         # profiles/r03_i_k2_effective_clock.txt).  GRBM_GUI_ACTIVE of the committed PMC profile / 8 XCDs / that profile's launch time:
+                         **({"effective_clock_hz_in_profile": pmk["GRBM_GUI_ACTIVE"] / 8.0 / (pmk["duration_ms"] * 1e-3),
+                             "clock_source": pmk["source"]} if pmk and "GRBM_GUI_ACTIVE" in pmk and pmk.get("duration_ms") else {})}}
 
     def survey_bytes_per_pair(wl_n):
         """(N L + 2 x N n_hash 4 + N^2 8) bytes per call / N (N - 1) / 2 unordered pairs"""

@@ -1185,16 +1185,23 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare_q12(const uint32_t
     const uint32_t oml = __builtin_amdgcn_readfirstlane((uint32_t)om), omh = __builtin_amdgcn_readfirstlane((uint32_t)(om >> 32));
     const uint32_t fl = __builtin_amdgcn_readfirstlane(flags), sp = __builtin_amdgcn_readfirstlane(phase * (uint32_t)(STAGE_UNITS * 16));
     const uint32_t pwu = __builtin_amdgcn_readfirstlane(pw);
+#ifdef K2Q_TIMING
+    uint32_t q_tw = 0, q_tbr = 0;
+    const unsigned long long q_t0 = __builtin_readcyclecounter();
+#endif
     asm volatile(
 #include K2_LOOP_INC_Q
         : "+v"(c64), "+v"(c65), "+v"(c66), "+v"(c67), "+v"(c68), "+v"(c69), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73), "+v"(c74),
           "+v"(c75), "+v"(c76), "+v"(c77), "+v"(c78), "+v"(c79), "+v"(c80), "+v"(c81), "+v"(c82), "+v"(c83), "+v"(c84), "+v"(c85),
           "+v"(c86), "+v"(c87), "+v"(c88), "+v"(c89), "+v"(c90), "+v"(c91), "+v"(c92), "+v"(c93), "+v"(c94), "+v"(c95)
+#ifdef K2Q_TIMING
+          , [tw] "=s"(q_tw), [tbr] "=s"(q_tbr)
+#endif
         : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh), [nl] "s"(nl),
           [nh] "s"(nh), [fl] "s"(fl), [sp] "s"(sp), [tb] "s"(tab_base), [nn] "s"(nn), [odl] "s"(odl), [odh] "s"(odh), [oml] "s"(oml),
           [omh] "s"(omh), [l8] "s"(l8), [pw] "s"(pwu), [kk] "s"(kk), "v"(r119), "v"(r120), "v"(r121), "v"(r124), "v"(r127)
         : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
-          "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "v125", "v126",
+          "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v125", "v126",
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
           "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
@@ -1204,6 +1211,14 @@ __global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare_q12(const uint32_t
           "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143",
           "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",
           "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
+#ifdef K2Q_TIMING
+    if (threadIdx.x == 0) {                                      // (timing build) wave 0's cycles: DMA wait, barrier wait, whole block, blocks
+      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[0]), (unsigned long long)q_tw);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[2]), (unsigned long long)q_tbr);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[4]), __builtin_readcyclecounter() - q_t0);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[6]), 1ull);
+    }
+#endif
     pw = (flags & 4u) ? 4u * kk : 0u;                            // stores per stage the block just issued
     prv = cur;
     cur = nxt;
@@ -1784,6 +1799,17 @@ static R12Inst *r12_acquire(R12Pool &P, int dev, bool need_scratch, int cus) {
   return inst;
 }
 
+#ifdef K2Q_TIMING
+extern "C" int da_debug_k2_inloop_timing(unsigned long long *out4) {   // (timing build) sums over all blocks of the device's last q12 launch
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DA_ERR_HIP;
+  R12Ctl *ctl;
+  { std::lock_guard<std::mutex> g(r12_pool().m); ctl = r12_pool().last_ctl[dev]; }
+  if (!ctl || hipDeviceSynchronize() != hipSuccess) return DA_ERR_HIP;
+  return hipMemcpy(out4, &ctl->published[0], 32, hipMemcpyDeviceToHost) == hipSuccess ? DA_OK : DA_ERR_HIP;
+}
+#endif
+
 // launches the role-split kernel (experiment, DYNAALIGN_K2_ROLES=1) or the in-loop-store kernel for the interior tiles of a symmetric
 // 12-plane float64 compare; *launched = false when it does not apply here (no free scratch instance, occupancy, ...) and the caller
 // should take k_mh_compare_a12
@@ -1820,7 +1846,11 @@ static int launch_persistent_f64(bool roles, const uint32_t *d_planes, int64_t n
     hipLaunchKernelGGL(k_mh_compare_r12, dim3((unsigned)(8 * wg_per_xcd)), dim3(K2_THREADS), 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd,
                        inst->ctl, inst->scratch, occ, inst->max_mbox, getenv("DYNAALIGN_K2_ROLES_DEBUG") ? atoi(getenv("DYNAALIGN_K2_ROLES_DEBUG")) : 0);
   } else {
+#ifdef K2Q_TIMING
+    DA_HIP_TRY(hipMemsetAsync(inst->ctl, 0, sizeof(R12Ctl), stream));
+#else
     DA_HIP_TRY(hipMemsetAsync(inst->ctl->next, 0, sizeof(inst->ctl->next), stream));      // the per-XCD tile counters are all it uses
+#endif
     hipLaunchKernelGGL(k_mh_compare_q12, dim3((unsigned)(8 * wg_per_xcd)), dim3(K2_THREADS), 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd,
                        inst->ctl);
   }

@@ -56,6 +56,7 @@ HALF_LAST = PLANES == 15                                            # the last s
 STAGE_BYTES = 256 * SEGS * 16  # 12288 (20480 with the padded 16-plane slots)
 ROW = 16 * SEGS * 16          # byte distance between the lane's rows / columns in LDS: 768 (1280)
 out = []
+QTIMING = int(os.environ.get("K2ASM_QTIMING", "0"))   # in-loop block: s_memtime around the DMA wait and the stage barrier, sums in s68 / s69 (asm outputs %[tw] / %[tbr])
 NOSTORE = int(os.environ.get("K2ASM_NOSTORE", "0"))   # experiments on the in-loop block: 1 = leave the global stores out, 2 = leave the table reads out
 def e(x):
     if NOSTORE == 1 and x.startswith("global_store"):
@@ -229,7 +230,16 @@ def gen_persistent():
     e("21:")
     e("s_waitcnt vmcnt(3)")
     e("4:")
+    if QTIMING:
+        e("s_memtime s[66:67]")
     e("s_barrier")
+    if QTIMING:
+        e("s_memtime s[70:71]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_sub_u32 s64, s66, s64")          # cycles in the vmcnt wait (+ the compare chain)
+        e("s_add_u32 s68, s68, s64")
+        e("s_sub_u32 s66, s70, s66")          # cycles at the barrier
+        e("s_add_u32 s69, s69, s66")
     e("v_add_u32 v116, %s, v120" % S_SLOT)
     e("v_add_u32 v117, %s, v121" % S_SLOT)
     b_read(0, 0, 0)
@@ -307,6 +317,9 @@ def gen_inloop():
     for r in range(8):
         for c2 in range(4):
             e("v_mov_b32 %s, 0" % mis(r, c2))
+    if QTIMING:
+        e("s_mov_b32 s68, 0")
+        e("s_mov_b32 s69, 0")
     e("s_mov_b32 %s, 0" % P)
     e("s_mov_b32 %s, %%[pw]" % W1)
     e("s_mov_b32 %s, %%[pw]" % W2)
@@ -386,6 +399,8 @@ def gen_inloop():
         e("s_nop 1")
 
     e("2:")
+    if QTIMING:
+        e("s_memtime s[64:65]")
     # ---- wait for this stage's DMA: allowed in flight = stores of the two previous stages + the next stage's DMA (if issued)
     e("s_add_u32 %s, %s, %s" % (S_TMP, W1, W2))
     e("s_add_u32 s58, %s, 1" % S_STAGE)
@@ -407,7 +422,16 @@ def gen_inloop():
         e("s_waitcnt vmcnt(%d)" % v)
         e("s_branch 4f")
     e("4:")
+    if QTIMING:
+        e("s_memtime s[66:67]")
     e("s_barrier")
+    if QTIMING:
+        e("s_memtime s[70:71]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_sub_u32 s64, s66, s64")          # cycles in the vmcnt wait (+ the compare chain)
+        e("s_add_u32 s68, s68, s64")
+        e("s_sub_u32 s66, s70, s66")          # cycles at the barrier
+        e("s_add_u32 s69, s69, s66")
     e("v_add_u32 v116, %s, v120" % S_SLOT)
     e("v_add_u32 v117, %s, v121" % S_SLOT)
     b_read(0, 0, 0)
@@ -475,6 +499,9 @@ def gen_inloop():
     count_group()
     if PRIO or EPRIO:
         e("s_setprio %d" % EPRIO)
+    if QTIMING:
+        e("s_mov_b32 %[tw], s68")
+        e("s_mov_b32 %[tbr], s69")
     e("s_mov_b32 m0, s47")
 
 def gen_16():

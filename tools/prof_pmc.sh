@@ -30,6 +30,13 @@ for f in glob.glob(os.path.join(out, "*", "*", "*counter_collection.csv")):
         m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Kernel_Name"])
         k = m.group(1) if m else r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# launch durations of the GRBM pass (same run as its counter): GRBM_GUI_ACTIVE / 8 XCDs / duration = the effective shader clock
+for f in glob.glob(os.path.join(out, "grbm", "*", "*kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        import re
+        m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Kernel_Name"])
+        k = m.group(1) if m else r["Kernel_Name"][:60]
+        agg[k]["duration_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 import json
 n = 100000
 argv = os.environ.get("BENCH_ARGS", "").split()
