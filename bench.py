@@ -332,6 +332,22 @@ def main():
                 "note": "index expansion of the U x U count table to the dense f64 N x N; frac = SURVEY 8(d)'s algorithmic bytes per unordered pair "
                         "x the pairs of one launch / its HIP-event duration; frac_kernel_bytes counts the kernel's own 2 B read + 16 B written per pair"}
 
+    def sparse_roofline(tile_ms, incidences, wl_n=n):
+        """roofline object of k_sp_tiles (the dominant kernel of the SPARSE route: inputs whose signatures rarely agree): it writes every
+        element of the dense f64 matrix once from a 128 x 128 count image built in LDS out of the tile's bucket of matching incidences"""
+        pairs_x = wl_n * (wl_n - 1) // 2
+        bytes_alg = pairs_x * survey_bytes_per_pair(wl_n)
+        bytes_x = wl_n * wl_n * 8 + incidences * 2
+        t = tile_ms * 1e-3
+        traffic = pmc_traffic("k_sp_tiles", wl_n)
+        return {"kernel": "k_sp_tiles", "bound": "hbm", "achieved": bytes_alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_alg / t / 1e9 / HBM_PEAK_GBS, "frac_kernel_bytes": bytes_x / t / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                "avg_launch_ms": tile_ms, "algorithmic_bytes_per_launch": bytes_alg, "kernel_bytes_per_launch": bytes_x,
+                "matching_incidences": incidences,
+                "note": "sparse route: the dictionary codes of K1b give the matching (pair, hash function) incidences; they are bucketed per output tile "
+                        "(phases_ms.k2_ms = that bucket phase) and every tile of the f64 matrix is written once (phases_ms.expand_ms = this kernel)"}
+
     def k2_roofline(k2_ms, plane_bits, wl_n=n, out_elem=8):
         """roofline object of the compare kernel: algorithmic bytes (with the plane words actually read) /
         HIP-event duration, against the 8 TB/s HBM peak; + the VALU bound that actually binds"""
@@ -380,6 +396,8 @@ def main():
     if world > 1 and state.get("dedup"):
         main_roof = expand_roofline(phases["expand"])
         main_roof["note"] += "; here avg_launch_ms is the whole expansion call (column gather + k_expand_rows + border tiles)"
+    elif world == 1 and route.get("sparse"):
+        main_roof = sparse_roofline(phases["expand_ms"], route["sparse_pairs"])
     elif world == 1 and route["dedup"]:
         # the timed step ran on the table of unique strings: its dominant kernel is the expansion; K2 on U rows rides along
         main_roof = expand_roofline(phases["expand_ms"])
@@ -407,15 +425,17 @@ def main():
         "phases_ms": phases,
     }
     if world == 1:
-        line["route"] = {"n": route["n"], "unique": route["unique"], "dedup": route["dedup"], "plane_bits": route["plane_bits"],
+        line["route"] = {"n": route["n"], "unique": route["unique"], "dedup": route["dedup"], "sparse": route.get("sparse", False), "plane_bits": route["plane_bits"],
                          "note": "dedup: byte-identical sequences collapsed (exact) -- K1 / K1b / K2 on the unique strings, then column gather + "
                                  "index expansion to the dense N x N; direct: the three kernels on all N rows"}
         if route["dedup"]:
-            os.environ["DYNAALIGN_MH_NO_DEDUP"] = "1"            # the same input with the route off: K2 on all N rows (what uniform peptides get)
+            os.environ["DYNAALIGN_MH_NO_DEDUP"] = "1"            # the same input with the routes off: K2 on all N rows
+            os.environ["DYNAALIGN_MH_NO_SPARSE"] = "1"
             try:
                 ddt, devs = timed_steps(step, max(2, min(a.steps, 3)), 1)
             finally:
                 del os.environ["DYNAALIGN_MH_NO_DEDUP"]
+                del os.environ["DYNAALIGN_MH_NO_SPARSE"]
             dsteps = max(2, min(a.steps, 3))
             dph = phase_means(devs)
             droof = k2_roofline(dph["k2_ms"], state["bits"])
@@ -593,12 +613,25 @@ def main():
         usteps = max(2, min(a.steps, 3))
         udt, uevs = timed_steps(lambda: step(uds), usteps, 1)
         uph = phase_means(uevs)
-        uroof = k2_roofline(uph["k2_ms"], state["bits"])
+        ulast = uevs[-1]
+        uroof = sparse_roofline(uph["expand_ms"], ulast["sparse_pairs"]) if ulast.get("sparse") else k2_roofline(uph["k2_ms"], state["bits"])
         uroof["step_frac"] = step_bytes / (udt / usteps) / 1e9 / HBM_PEAK_GBS
         line["uniform"] = {"workload": "similarityMH k=4 n_hash=500 on %d uniform 20-mers (SURVEY 8(d) S100k), dense f64 NxN in HBM" % n,
                            "value": pairs_mh / (udt / usteps), "unit": "pairs/s", "ms_per_step": udt / usteps * 1e3, "steps": usteps,
-                           "plane_bits": state["bits"], "phases_ms": uph, "route": {"unique": uevs[-1]["unique"], "dedup": uevs[-1]["dedup"]},
+                           "plane_bits": state["bits"], "phases_ms": uph,
+                           "route": {"unique": ulast["unique"], "dedup": ulast["dedup"], "sparse": ulast.get("sparse", False),
+                                     "matching_incidences": ulast.get("sparse_pairs", 0)},
                            "roofline": uroof}
+        if ulast.get("sparse"):                                  # the dense kernels on the same input, for reference (what round 2 reported here)
+            os.environ["DYNAALIGN_MH_NO_SPARSE"] = "1"
+            try:
+                ddt2, devs2 = timed_steps(lambda: step(uds), 2, 1)
+            finally:
+                del os.environ["DYNAALIGN_MH_NO_SPARSE"]
+            dph2 = phase_means(devs2)
+            line["uniform"]["dense_kernels"] = {"ms_per_step": ddt2 / 2 * 1e3, "phases_ms": dph2, "plane_bits": state["bits"],
+                                                "roofline": k2_roofline(dph2["k2_ms"], state["bits"]),
+                                                "note": "DYNAALIGN_MH_NO_SPARSE=1: K1 / K1b / K2 (bit-sliced compare of every pair)"}
         del uds
 
     # ---- BASELINE configs[4]: clusterbreak(size_max=800, thresh_p=.8) end to end, GPU similarityMH backend on the

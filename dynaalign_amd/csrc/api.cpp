@@ -475,9 +475,13 @@ static int env_plane_bits() {   // DYNAALIGN_PLANE_BITS: 32 = raw planes, 12 / 1
   const int v = e ? atoi(e) : 0;
   return (v == 32 || v == 16 || v == 15 || v == 14 || v == 12) ? v : 0;
 }
+// The sparse route (minhash_kernels.hip "SPARSE route"): the caller of build_planes asks for it by passing a SparseHint; when the
+// dictionary says the signatures rarely agree (few matching incidences, no large class) build_planes returns with take = true and
+// WITHOUT building the bit planes -- the caller then runs launch_mh_sparse on the dictionary codes in the workspace.
+struct SparseHint { bool take = false; int max_ids = 0; uint64_t pairs = 0, max_mult = 0; };
 // min_bits: 0 = as few code planes as the data needs, 12 / 16 = at least that many, 32 = raw planes
 static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, int min_bits, void *d_work,
-                        size_t work_bytes, uint32_t *d_planes, int *bits_out, hipStream_t stream) {
+                        size_t work_bytes, uint32_t *d_planes, int *bits_out, hipStream_t stream, SparseHint *sparse = nullptr) {
   int rc;
   const int env = env_plane_bits();
   if (env > min_bits) min_bits = env;
@@ -489,6 +493,25 @@ static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_
     int status[2] = {0, 0};
     DA_HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, stream));
     DA_HIP_TRY(hipStreamSynchronize(stream));
+    if (sparse && status[0] == 0 && status[1] >= 1 && status[1] <= 32768 && min_bits == 0 && n >= 2048 && n_hash + 1 <= 2048 &&
+        !getenv("DYNAALIGN_MH_NO_SPARSE")) {
+      // how many (pair, hash function) incidences match, and how large is the largest class?  (one more read-back: ~0.15 ms)
+      int64_t ld_ids = 0;
+      const uint16_t *ids = mh_dictionary_codes(d_work, n, n_hash, &ld_ids);
+      unsigned long long *d_stats = reinterpret_cast<unsigned long long *>(d_status + 4);     // behind the two status words (the workspace ends 256 bytes later)
+      if ((rc = launch_mh_sparse_count(ids, ld_ids, n, n_hash, status[1], d_stats, stream)) != DA_OK) return rc;
+      unsigned long long st[2] = {0, 0};
+      DA_HIP_TRY(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, stream));
+      DA_HIP_TRY(hipStreamSynchronize(stream));
+      sparse->pairs = st[0]; sparse->max_mult = st[1]; sparse->max_ids = status[1];
+      // admission: the bucket phase costs ~37 ps per incidence (5.1 ms for 1.37e8) and the tile pass ~2.5 ps per pair, the dense compare ~6.3 ps
+      // per pair at n_hash = 500 -- so the route pays while the average number of matches per pair stays below ~0.1 (x n_hash / 500);
+      // plus a memory cap on the bucket and a cap on the class size (a thread walks its class)
+      const double pairs_all = 0.5 * (double)n * (double)(n - 1);
+      if (st[0] <= mh_sparse_pairs_limit() && st[1] <= 4096 && (double)st[0] <= pairs_all * (double)n_hash / 5000.0) {
+        sparse->take = true; *bits_out = 0; return DA_OK;
+      }
+    }
     if (status[0] == 0) {
       int bits = mh_plane_bits_for(status[1]);
       if (bits < min_bits) bits = min_bits;
@@ -595,9 +618,33 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   if ((rc = pwork.alloc(wb)) != DA_OK) return rc;
   if ((rc = launch_minhash_signatures(res_m, off_m, m, k, n_hash, d_seeds, sig.as<uint32_t>(), lds, stream)) != DA_OK) return rc;
   int bits = 32;
-  if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream)) != DA_OK) return rc;
+  SparseHint sp;
+  // the sparse route is only worth asking about when the input has few duplicates (clustered inputs have large classes: the dense kernels win)
+  const bool ask_sparse = !take && U * 10 >= n * 9;
+  if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream, ask_sparse ? &sp : nullptr)) != DA_OK) return rc;
   route.plane_bits = bits;
   DA_HIP_TRY(hipEventRecord(ev[2], stream));
+  if (!take && sp.take) {
+    // SPARSE route: the signatures rarely agree -- the matching incidences are enumerated from the dictionary codes, bucketed per output
+    // tile and every tile written once (exact; minhash_kernels.hip).  ms[2] = link + walk + scan (buckets), ms[4] = the tile pass.
+    int64_t ld_ids = 0;
+    const uint16_t *ids = mh_dictionary_codes(pwork.p, n, n_hash, &ld_ids);
+    DevBuf scratch, entries32, entries;
+    if ((rc = scratch.alloc(mh_sparse_scratch_words(n, n_hash, sp.max_ids, ld_ids) * 4)) != DA_OK) return rc;
+    if ((rc = entries32.alloc((size_t)sp.pairs * 4 + 16)) != DA_OK) return rc;
+    if ((rc = entries.alloc((size_t)sp.pairs * 2 + 16)) != DA_OK) return rc;
+    if ((rc = launch_mh_sparse(ids, ld_ids, n, n_hash, sp.max_ids, sp.pairs, scratch.as<uint32_t>(), entries32.as<uint32_t>(), entries.as<uint16_t>(), d_out, ld,
+                               stream, ev[3])) != DA_OK) return rc;
+    DA_HIP_TRY(hipEventRecord(ev[4], stream));
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+    route.taken = 2;
+    route.unique = (int64_t)sp.pairs;                               // (reported as `sparse_pairs` by the Python wrapper)
+    (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
+    (void)hipEventElapsedTime(&route.ms[1], ev[1], ev[2]);
+    (void)hipEventElapsedTime(&route.ms[2], ev[2], ev[3]);
+    (void)hipEventElapsedTime(&route.ms[4], ev[3], ev[4]);
+    return DA_OK;
+  }
   if (!take) {
     if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, DA_OUT_F64, d_out, ld, stream, bits)) != DA_OK) return rc;
     DA_HIP_TRY(hipEventRecord(ev[3], stream));

@@ -114,6 +114,14 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
                       void *d_out, int64_t ld, hipStream_t stream, int plane_bits = 32, int tile_stride = 1,
                       bool upper_only = false, int fold_q = 0, int64_t fold_w = 0);
+// minhash_kernels.hip, SPARSE route of the symmetric float64 compare (inputs whose signatures rarely agree): see the kernels' header comment
+size_t mh_sparse_pairs_limit();
+int launch_mh_sparse_count(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, unsigned long long *d_stats, hipStream_t stream);
+size_t mh_sparse_scratch_words(int64_t n, int n_hash, int max_ids, int64_t ld_ids);
+int launch_mh_sparse(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, uint64_t pairs, uint32_t *d_scratch,
+                     uint32_t *d_entries32, uint16_t *d_entries, double *d_out, int64_t ld, hipStream_t stream, hipEvent_t after_buckets = nullptr);
+// dict_kernels.hip: where the codes of launch_mh_dictionary sit in its workspace ([n_hash][*ld_ids] uint16, 0xFFFF = value seen once)
+const uint16_t *mh_dictionary_codes(const void *d_work, int64_t n, int n_hash, int64_t *ld_ids);
 // frees the idle scratch instances of the role-split compare kernel (da_release_device_memory); returns the bytes freed
 size_t release_compare_scratch();
 // dict_kernels.hip: signatures -> compare operand.  Dictionary codes (8 / 12 / 16 planes per group,

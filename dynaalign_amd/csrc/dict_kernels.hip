@@ -286,6 +286,11 @@ size_t mh_planes_workspace_bytes(int64_t n, int n_hash) {
   return (size_t)n_hash * ldT * (4 + 4 + 4 + 2) + 256;   // sigT, sorted keys, their indices, codes, status
 }
 
+const uint16_t *mh_dictionary_codes(const void *d_work, int64_t n, int n_hash, int64_t *ld_ids) {
+  *ld_ids = dict_ldT(n);
+  return dict_work(const_cast<void *>(d_work), n, n_hash).idsT;
+}
+
 // Step 1 (transpose + dictionary): leaves the codes and two status words in the workspace.
 // *d_status_out points at them; read them once the stream has drained, pick the plane count
 // (mh_plane_bits_for) and run step 2.

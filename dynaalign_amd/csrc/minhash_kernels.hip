@@ -2598,6 +2598,287 @@ int launch_shards_to_table(const void *d_g, int64_t ld_g, const ShardGeom &geom,
   return DA_OK;
 }
 
+// ---- SPARSE route of the symmetric float64 compare (round 3) --------------------------------------------------------------
+// For inputs whose signatures rarely agree (uniform random peptides at N = 100k: 1.4*10^8 matching (pair, hash function)
+// incidences against 2.5*10^12 compared ones) the bit-sliced compare spends 31 ms finding that almost every count is zero.  The
+// dictionary codes of K1b already say which sequences share a value in a column; so, exactly:
+//   k_sp_count   per column: multiplicity of every repeated value (LDS histogram) -> E = sum m (m - 1) / 2 and the largest m; the host
+//                takes the route when E and m are small (da_dev_similarity_mh; DYNAALIGN_MH_SPARSE_MAX_PAIRS)
+//   k_sp_link    per (column, sequence): a linked list per repeated value (atomicExch on the value's head)
+//   k_sp_walk    per (column, sequence): walk the list behind the sequence = the partners inserted before it -> every matching
+//                incidence (i < j, column) once; pass 0 counts them per 128 x 128 output tile, pass 1 (after a scan) drops them into
+//                the tile's bucket as 14-bit local coordinates
+//   k_sp_tiles   per output tile on or above the diagonal: the incidences are added into a 128 x 128 uint16 image in LDS (integer
+//                atomics), then the tile and its mirror image are written as float64 through the count -> double table -- the same
+//                streaming-store epilogue as k_expand_rows (er_store_tile); diagonal / border tiles element by element.
+// Every element of the result is written exactly once; counts are integers until the table lookup: bit-identical to the dense kernels.
+constexpr int SP_MAX_IDS = 32768;            // LDS histogram of a column's repeated values (uint32 each: 128 KiB)
+__global__ __launch_bounds__(1024) void k_sp_count(const uint16_t *__restrict__ idsT, int64_t ld_ids, int n, int max_ids,
+                                                   unsigned long long *__restrict__ stats) {
+  extern __shared__ uint32_t sp_hist[];
+  const uint16_t *ids = idsT + (int64_t)blockIdx.x * ld_ids;
+  for (int c = threadIdx.x; c < max_ids; c += 1024) sp_hist[c] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const uint32_t c = ids[i];
+    if (c != 0xFFFFu) atomicAdd(&sp_hist[c], 1u);
+  }
+  __syncthreads();
+  unsigned long long e = 0, mx = 0;
+  for (int c = threadIdx.x; c < max_ids; c += 1024) {
+    const unsigned long long m = sp_hist[c];
+    e += m * (m - (m ? 1 : 0)) / 2;
+    mx = m > mx ? m : mx;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    e += __shfl_down(e, o);
+    const unsigned long long other = __shfl_down(mx, o);
+    mx = other > mx ? other : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], e); atomicMax(&stats[1], mx); }
+}
+// Per column: the members of every repeated value, class after class (a counting sort by code in LDS -- no global atomics):
+//   cstart[h][c] .. cstart[h][c + 1]  = where class c's members sit in member[h][.]
+__global__ __launch_bounds__(1024) void k_sp_classes(const uint16_t *__restrict__ idsT, int64_t ld_ids, int n, int max_ids, int cs_ld,
+                                                     uint32_t *__restrict__ cstart, uint32_t *__restrict__ member) {
+  extern __shared__ uint32_t sp_hist[];        // max_ids counters, then 1024 partial sums
+  uint32_t *part = sp_hist + max_ids;
+  const uint16_t *ids = idsT + (int64_t)blockIdx.x * ld_ids;
+  uint32_t *cs = cstart + (int64_t)blockIdx.x * cs_ld, *mem = member + (int64_t)blockIdx.x * ld_ids;
+  for (int c = threadIdx.x; c < max_ids; c += 1024) sp_hist[c] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const uint32_t c = ids[i];
+    if (c != 0xFFFFu) atomicAdd(&sp_hist[c], 1u);
+  }
+  __syncthreads();
+  const int per = (max_ids + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < max_ids ? lo + per : max_ids;
+  uint32_t sum = 0;
+  for (int c = lo; c < hi; ++c) sum += sp_hist[c];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x < 64) {                      // exclusive scan of the 1024 partial sums by one wave (16 each)
+    uint32_t v[16], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { v[q] = part[threadIdx.x * 16 + q]; tot += v[q]; }
+    uint32_t incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += up; }
+    uint32_t run = incl - tot;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { part[threadIdx.x * 16 + q] = run; run += v[q]; }
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (int c = lo; c < hi; ++c) { const uint32_t v = sp_hist[c]; cs[c] = run; sp_hist[c] = run; run += v; }
+  if (hi == max_ids && lo < hi) cs[max_ids] = run;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const uint32_t c = ids[i];
+    if (c != 0xFFFFu) mem[atomicAdd(&sp_hist[c], 1u)] = (uint32_t)i;
+  }
+}
+__device__ __forceinline__ int64_t sp_tile_index(int ti, int tj, int T) { return (int64_t)ti * T - (int64_t)ti * (ti - 1) / 2 + (tj - ti); }
+// Per (column, sequence i): the class partners j > i = the matching incidences (i, j, column), each once, emitted from the side of the
+// SMALLER index -- so a block of 256 consecutive i feeds exactly two 128-row bands of the output and needs one global atomic per band
+// to reserve its space.  PASS 0 sizes the bands, PASS 1 (after a scan of the 782 band sizes) writes (i & 127) << 17 | j.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sp_emit(const uint16_t *__restrict__ idsT, int64_t ld_ids, int n, int cs_ld, const uint32_t *__restrict__ cstart,
+                                                 const uint32_t *__restrict__ member, uint32_t *__restrict__ band_cnt,
+                                                 const uint32_t *__restrict__ band_start, uint32_t *__restrict__ entries32,
+                                                 uint16_t *__restrict__ saved_cnt) {
+  __shared__ uint32_t blk[4];
+  const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, bl = threadIdx.x >> 7;
+  if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t lo = 0, hi = 0, cnt = 0;
+  const uint32_t *mem = member + (int64_t)h * ld_ids;
+  if (i < n) {
+    const uint32_t c = idsT[(int64_t)h * ld_ids + i];
+    if (c != 0xFFFFu) { lo = cstart[(int64_t)h * cs_ld + c]; hi = cstart[(int64_t)h * cs_ld + c + 1]; }
+    if (PASS == 0) {
+      for (uint32_t k = lo; k < hi; ++k) cnt += mem[k] > (uint32_t)i;
+      saved_cnt[(int64_t)h * ld_ids + i] = (uint16_t)cnt;          // (a class has at most 4096 members: the route's admission rule)
+    } else {
+      cnt = saved_cnt[(int64_t)h * ld_ids + i];
+    }
+  }
+  const uint32_t off = cnt ? atomicAdd(&blk[bl], cnt) : 0u;
+  __syncthreads();
+  const int band = 2 * blockIdx.x + bl;
+  if (PASS == 0) {
+    if ((threadIdx.x & 127) == 0 && blk[bl]) atomicAdd(&band_cnt[band], blk[bl]);
+    return;
+  }
+  if ((threadIdx.x & 127) == 0 && blk[bl]) blk[2 + bl] = band_start[band] + atomicAdd(&band_cnt[band], blk[bl]);   // band_cnt: cursors (zeroed again)
+  __syncthreads();
+  if (!cnt) return;
+  uint32_t w = blk[2 + bl] + off;
+  for (uint32_t k = lo; k < hi; ++k) {
+    const uint32_t j = mem[k];
+    if (j > (uint32_t)i) entries32[w++] = ((uint32_t)(i & 127) << 17) | j;
+  }
+}
+// exclusive scan of `count` values by one workgroup: start[t] (and cnt[t] = 0 for its second life as a cursor), start[count] = total
+__global__ __launch_bounds__(1024) void k_sp_scan(uint32_t *__restrict__ cnt, uint32_t *__restrict__ start, int64_t count) {
+  __shared__ uint32_t part[1024];
+  const int64_t per = (count + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < count ? lo + per : count;
+  uint32_t s = 0;
+  for (int64_t t = lo; t < hi; ++t) s += cnt[t];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 0; k < 1024; ++k) { const uint32_t v = part[k]; part[k] = run; run += v; } }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (int64_t t = lo; t < hi; ++t) { const uint32_t v = cnt[t]; start[t] = run; cnt[t] = 0; run += v; }
+  if (threadIdx.x == 1023) start[count] = run;
+}
+// Per band (128 output rows): its incidences sorted by tile column in LDS (histogram, scan, cursors: LDS atomics only) -> the tiles' start
+// offsets and the final 14-bit entries (row & 127) << 7 | (column & 127)
+__global__ __launch_bounds__(1024) void k_sp_band(const uint32_t *__restrict__ band_start, const uint32_t *__restrict__ entries32, int T,
+                                                  uint32_t *__restrict__ start, uint16_t *__restrict__ entries) {
+  __shared__ uint32_t hist[1024];
+  const int ti = blockIdx.x;
+  const uint32_t lo = band_start[ti], hi = band_start[ti + 1];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += 4096) {     // four loads in flight per thread: the loop is latency-bound otherwise
+    uint32_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = e + q * 1024 < hi ? entries32[e + q * 1024] : 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (v[q] != 0xffffffffu) atomicAdd(&hist[(v[q] & 0x1ffffu) >> 7], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                      // exclusive scan of the 1024 counters by one wave (16 each)
+    uint32_t v[16], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { v[q] = hist[threadIdx.x * 16 + q]; tot += v[q]; }
+    uint32_t incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += up; }
+    uint32_t run = incl - tot;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { hist[threadIdx.x * 16 + q] = run; run += v[q]; }
+  }
+  __syncthreads();
+  const int tj = threadIdx.x;
+  if (tj >= ti && tj < T) start[sp_tile_index(ti, tj, T)] = lo + hist[tj];
+  if (ti == T - 1 && threadIdx.x == 0) start[sp_tile_index(T - 1, T - 1, T) + 1] = hi;
+  __syncthreads();
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += 4096) {
+    uint32_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = e + q * 1024 < hi ? entries32[e + q * 1024] : 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (v[q] != 0xffffffffu) {
+        const uint32_t j = v[q] & 0x1ffffu;
+        entries[lo + atomicAdd(&hist[j >> 7], 1u)] = (uint16_t)(((v[q] >> 17) << 7) | (j & 127u));
+      }
+  }
+}
+__global__ __launch_bounds__(256, 4) void k_sp_tiles(const uint32_t *__restrict__ start, const uint16_t *__restrict__ entries, int n, int n_hash,
+                                                     int tab_entries, double *__restrict__ out, int64_t ld, int T, int64_t ntiles, int64_t per_xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char er_lds[];   // 128 x ER_STRIDE uint16 image, then the count -> double table
+  double *tab = reinterpret_cast<double *>(er_lds + 128 * ER_STRIDE);
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= ntiles) return;
+  const TileId tt = decode_tile(L, T, T, true);
+  if (!tt.valid) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  uint32_t *img = reinterpret_cast<uint32_t *>(er_lds);
+  for (int w = tid; w < 128 * ER_STRIDE / 4; w += 256) img[w] = 0u;
+  for (int e = tid; e < tab_entries; e += 256) tab[e] = (double)e / (double)n_hash;            // src/minHash.cpp:174
+  __syncthreads();
+  const int64_t t = sp_tile_index(tt.ti, tt.tj, T);
+  const uint32_t e0 = start[t], e1 = start[t + 1];
+  for (uint32_t e = e0 + tid; e < e1; e += 256) {
+    const uint32_t v = entries[e], r = v >> 7, c = v & 127u;
+    atomicAdd(&img[(r * ER_STRIDE + (c >> 1) * 4) / 4], 1u << (16 * (c & 1u)));                // two uint16 counts per word: no carry below 65536
+  }
+  __syncthreads();
+  const int64_t I0 = (int64_t)tt.ti * 128, J0 = (int64_t)tt.tj * 128;
+  if (expand_fast_takes(tt.ti, tt.tj, n, ld, out)) {
+    const int tx = ((wave & 1) << 3) + (lane & 7), ty = ((wave >> 1) << 3) + (lane >> 3);
+    er_store_tile(er_lds, [&](uint32_t x) -> double { return tab[x]; }, out, ld, I0, J0, tx, ty);
+    return;
+  }
+  // diagonal / border tiles: element by element (the image holds i < j only: the diagonal tile's lower half comes from its upper)
+  const uint16_t *img16 = reinterpret_cast<const uint16_t *>(er_lds);
+  for (int q = tid; q < 128 * 128; q += 256) {
+    const int r = q >> 7, c = q & 127;
+    const int64_t i = I0 + r, j = J0 + c;
+    if (i >= n || j >= n) continue;
+    if (tt.ti == tt.tj) {
+      const uint32_t v = r == c ? (uint32_t)n_hash : img16[(r < c ? r : c) * (ER_STRIDE / 2) + (r < c ? c : r)];   // diagonal: src/minHash.cpp:161
+      out[i * ld + j] = tab[v];
+    } else {
+      const double v = tab[img16[r * (ER_STRIDE / 2) + c]];
+      out[i * ld + j] = v;
+      out[j * ld + i] = v;
+    }
+  }
+}
+
+size_t mh_sparse_pairs_limit() {
+  if (const char *e = getenv("DYNAALIGN_MH_SPARSE_MAX_PAIRS")) return (size_t)strtoull(e, nullptr, 10);
+  return (size_t)400000000;
+}
+// stats[0] = matching (pair, hash function) incidences, stats[1] = largest multiplicity of a value in a column; both zeroed here
+int launch_mh_sparse_count(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, unsigned long long *d_stats, hipStream_t stream) {
+  if (max_ids < 1 || max_ids > SP_MAX_IDS || n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "sparse count: too many repeated values per column");
+  static std::atomic<uint64_t> attr_done;
+  int dev = 0;
+  DA_HIP_TRY(hipGetDevice(&dev));
+  if (!((attr_done.load() >> (dev & 63)) & 1u)) {
+    DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_count), hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_IDS * 4));
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  DA_HIP_TRY(hipMemsetAsync(d_stats, 0, 16, stream));
+  hipLaunchKernelGGL(k_sp_count, dim3((unsigned)n_hash), dim3(1024), (size_t)max_ids * 4, stream, d_idsT, ld_ids, (int)n, max_ids, d_stats);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+// scratch the sparse route needs besides the two entry lists (uint32 words): class starts [n_hash][cs_ld], members [n_hash][ld_ids], band
+// counters + starts, tile starts
+size_t mh_sparse_scratch_words(int64_t n, int n_hash, int max_ids, int64_t ld_ids) {
+  const int64_t T = ceil_div(n, 128), ntiles = T * (T + 1) / 2;
+  return (size_t)n_hash * (size_t)((max_ids + 1 + 63) / 64 * 64) + (size_t)n_hash * (size_t)ld_ids + 2 * (size_t)(T + 64) + (size_t)(ntiles + 64) +
+         (size_t)n_hash * (size_t)ld_ids / 2 + 64;      // ... + the per-(column, sequence) partner counts pass 0 leaves for pass 1 (uint16)
+}
+// d_entries32: `pairs` uint32, d_entries: `pairs` uint16
+int launch_mh_sparse(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, uint64_t pairs, uint32_t *d_scratch,
+                     uint32_t *d_entries32, uint16_t *d_entries, double *d_out, int64_t ld, hipStream_t stream, hipEvent_t after_buckets) {
+  if (n > 131072 || n_hash + 1 > 2048 || pairs > 0xfffffff0ull || max_ids < 1 || max_ids > SP_MAX_IDS)
+    return fail(DA_ERR_UNSUPPORTED, "sparse route: shape not covered");
+  const int T = (int)ceil_div(n, 128);
+  const int64_t ntiles = (int64_t)T * (T + 1) / 2;
+  const int cs_ld = (max_ids + 1 + 63) / 64 * 64;
+  uint32_t *cstart = d_scratch, *member = cstart + (size_t)n_hash * cs_ld, *band_cnt = member + (size_t)n_hash * ld_ids, *band_start = band_cnt + T + 64,
+           *start = band_start + T + 64;
+  uint16_t *saved = reinterpret_cast<uint16_t *>(start + ntiles + 64);
+  static std::atomic<uint64_t> attr_done;
+  int dev = 0;
+  DA_HIP_TRY(hipGetDevice(&dev));
+  if (!((attr_done.load() >> (dev & 63)) & 1u)) {
+    DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_classes), hipFuncAttributeMaxDynamicSharedMemorySize, (SP_MAX_IDS + 1024) * 4));
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  DA_HIP_TRY(hipMemsetAsync(band_cnt, 0, (size_t)(T + 64) * 4, stream));
+  hipLaunchKernelGGL(k_sp_classes, dim3((unsigned)n_hash), dim3(1024), (size_t)(max_ids + 1024) * 4, stream, d_idsT, ld_ids, (int)n, max_ids, cs_ld, cstart, member);
+  const dim3 grid((unsigned)ceil_div(n, 256), (unsigned)n_hash);
+  hipLaunchKernelGGL(k_sp_emit<0>, grid, dim3(256), 0, stream, d_idsT, ld_ids, (int)n, cs_ld, cstart, member, band_cnt, band_start, d_entries32, saved);
+  hipLaunchKernelGGL(k_sp_scan, dim3(1), dim3(1024), 0, stream, band_cnt, band_start, (int64_t)T);
+  hipLaunchKernelGGL(k_sp_emit<1>, grid, dim3(256), 0, stream, d_idsT, ld_ids, (int)n, cs_ld, cstart, member, band_cnt, band_start, d_entries32, saved);
+  hipLaunchKernelGGL(k_sp_band, dim3((unsigned)T), dim3(1024), 0, stream, band_start, d_entries32, T, start, d_entries);
+  if (after_buckets) DA_HIP_TRY(hipEventRecord(after_buckets, stream));
+  const int64_t px = ceil_div(ntiles, 8);
+  const int entries = n_hash + 1;
+  hipLaunchKernelGGL(k_sp_tiles, dim3((unsigned)(px * 8)), dim3(256), 128 * ER_STRIDE + (size_t)entries * 8, stream, start, d_entries, (int)n, n_hash,
+                     entries, d_out, ld, T, ntiles, px);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
 int launch_symmetrize(void *d_mat, int64_t n, int64_t ld, int kind, hipStream_t stream) {
   if (n <= 1) return DA_OK;
   const unsigned t = (unsigned)ceil_div(n, 32);

@@ -292,7 +292,11 @@ def mh_last_route():
     ms = (ctypes.c_double * 6)()
     _capi.check(_capi.load().da_mh_last_route(ctypes.addressof(n), ctypes.addressof(u), ctypes.addressof(t), ctypes.addressof(b),
                                               ctypes.addressof(ms)))
-    return {"n": n.value, "unique": u.value, "dedup": bool(t.value), "plane_bits": b.value, "plan_ms": ms[0], "codes_ms": ms[1],
+    # route 1 = duplicate-collapsing, 2 = sparse (signatures rarely agree: matching incidences bucketed per tile; then `unique` carries their
+    # number, k2_ms the bucket phase and expand_ms the tile pass), 0 = the direct kernels
+    sparse = t.value == 2
+    return {"n": n.value, "unique": n.value if sparse else u.value, "dedup": t.value == 1, "sparse": sparse,
+            "sparse_pairs": u.value if sparse else 0, "plane_bits": b.value, "plan_ms": ms[0], "codes_ms": ms[1],
             "k2_ms": ms[2], "gather_ms": ms[3], "expand_ms": ms[4], "border_ms": ms[5]}
 
 

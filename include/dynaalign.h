@@ -221,6 +221,12 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
  * the stream.  DYNAALIGN_MH_NO_DEDUP=1 disables the route.  da_mh_last_route reports what the calling thread's last such
  * call did: n, unique strings, whether the route was taken, the plane count K1b chose, and the times in ms of
  * {plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles} (direct route: {plan, K1 + K1b, K2, 0, 0, 0}).
+ * A second exact route serves inputs without duplicates whose signatures rarely agree (uniform random peptides: 1.4e8 matching
+ * (pair, hash function) incidences at n = 100k against 2.5e12 compared ones): the dictionary codes of K1b say which sequences
+ * share a value in a column; those incidences are enumerated, bucketed per 128 x 128 output tile, added up in LDS and every tile
+ * is written once.  Taken when the input has few duplicates (>= 90 % unique), the incidences number <= n_hash / 5000 per pair on average and
+ * <= DYNAALIGN_MH_SPARSE_MAX_PAIRS (default 4e8) in all, no value occurs more than 4096 times in a column, <= 32768 repeated values per column, n >= 2048, n_hash <= 2047; DYNAALIGN_MH_NO_SPARSE=1 disables it.
+ * Then *dedup_taken_out = 2, *unique_out = the number of incidences and the times are {plan, K1 + K1b, buckets, 0, tile pass, 0}.
  * Any pointer may be NULL. */
 int da_dev_similarity_mh(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n, int64_t total_residues,
                          int k, int n_hash, const uint32_t *d_seeds, double *d_out, int64_t ld, void *stream);

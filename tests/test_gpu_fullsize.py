@@ -12,6 +12,8 @@ where the oracle can afford it, and the N > 1 legs of the sharded path rehearsed
     rows x leading dimension exceeds 2^31.
 
 Two float64 N x N buffers (2 x 80 GB) live for the whole module; torch is the checker's plumbing (allocation, compares)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,7 +121,8 @@ def test_uniform_100k_count_rows_against_the_oracle(da, bufs):
     out.fill_(-1.0)
     device.similarity_mh(ds, K, N_HASH, seeds, out=out)
     route = device.mh_last_route()
-    assert not route["dedup"] and route["plane_bits"] in (14, 15, 16)
+    # uniform random peptides: 1.4e8 matching (pair, hash function) incidences -> the SPARSE route (round 3)
+    assert not route["dedup"] and route["sparse"] and route["sparse_pairs"] > 0
     ratio = np.arange(N_HASH + 1, dtype=np.float64) / N_HASH
 
     def rows_of(a, b):
@@ -142,6 +145,18 @@ def test_uniform_100k_count_rows_against_the_oracle(da, bufs):
     for r0 in range(0, N, 5000):
         got += int(torch.round(out[r0:r0 + 5000] * N_HASH).to(torch.int64).sum().item())
     assert got == total
+    assert route["sparse_pairs"] == (total - N * N_HASH) // 2          # the route's incidence count is the same sum, off the diagonal, i < j
+    # ... and the dense kernels (15-bit dictionary codes -> the hand-scheduled 16-plane kernel) over the whole matrix, bit for bit
+    ref, _ = bufs
+    os.environ["DYNAALIGN_MH_NO_SPARSE"] = "1"
+    try:
+        ref.fill_(-1.0)
+        device.similarity_mh(ds, K, N_HASH, seeds, out=ref)
+        r2 = device.mh_last_route()
+    finally:
+        del os.environ["DYNAALIGN_MH_NO_SPARSE"]
+    assert not r2["sparse"] and not r2["dedup"] and r2["plane_bits"] in (14, 15, 16)
+    _same_bits(out, ref)
 
 
 def _virtual_mh_direct(h3n2, planes, world, packed, out):

@@ -201,3 +201,64 @@ def test_threshold_and_edges_through_the_row_map(da, n_draw, n_single):
     cg, ag = as_set(got)
     cw, aw = as_set(want)
     assert cg == cw == cap and np.array_equal(ag, aw)
+
+
+# ---- the SPARSE route (round 3): inputs without duplicates whose signatures rarely agree -----------------------------------------
+
+def _rand_peptides(n, lo, hi, seed, alphabet=b"ACDEFGHIKLMNPQRSTVWY"):
+    rng = np.random.RandomState(seed)
+    alpha = np.frombuffer(alphabet, np.uint8)
+    return ["".join(map(chr, alpha[rng.randint(0, len(alpha), rng.randint(lo, hi + 1))])) for _ in range(n)]
+
+
+@pytest.mark.parametrize("n,lo,hi,k,n_hash", [(2048, 20, 20, 4, 500), (2500, 12, 30, 4, 500), (4099, 20, 20, 4, 33), (3000, 8, 24, 5, 128),
+                                              (2600, 20, 20, 4, 2047)])
+def test_sparse_route_equals_the_oracle(da, n, lo, hi, k, n_hash):
+    """da_dev_similarity_mh on duplicate-free random peptides takes the sparse route (matching incidences enumerated from the dictionary
+    codes, bucketed per output tile, every tile written once): bit-identical to the oracle -- n a multiple of 128 or not (border tiles),
+    ragged lengths incl. sequences shorter than k (their all-ones signatures agree with each other in EVERY column: a large class),
+    n_hash from one stage to the table limit"""
+    import torch
+    from dynaalign_amd import device
+    seqs = _rand_peptides(n, lo, hi, seed=n + n_hash)
+    for t in (5, 77, 1234):
+        seqs[t] = seqs[t][:max(k - 1, 0)]                     # shorter than k: no k-mers (src/minHash.cpp:98-103)
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(res, off)
+    seeds = da.hash_family_seeds(12345, n_hash)
+    out = device.similarity_mh(ds, k, n_hash, seeds)
+    torch.cuda.synchronize()
+    route = device.mh_last_route()
+    assert route["sparse"] and not route["dedup"], route
+    rc, want = O.similarity_mh(seqs, k, n_hash, seeds)
+    assert rc == 0 and np.array_equal(out.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    assert route["sparse_pairs"] == int(np.triu(np.round(want * n_hash).astype(np.int64), 1).sum())
+
+
+def test_sparse_route_admission_rule_and_switch(da, monkeypatch):
+    """dense similarity structure (k = 1: every sequence shares letters with every other) is refused by the route's admission rule;
+    DYNAALIGN_MH_SPARSE_MAX_PAIRS / DYNAALIGN_MH_NO_SPARSE steer it; every way the same matrix"""
+    import torch
+    from dynaalign_amd import device
+    seqs = _rand_peptides(2300, 20, 20, seed=3)
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(res, off)
+    seeds = da.hash_family_seeds(7, 200)
+    a = device.similarity_mh(ds, 1, 200, seeds)
+    torch.cuda.synchronize()
+    assert not device.mh_last_route()["sparse"]                # k = 1: 2300 x 2300 x 200 incidences, classes of hundreds
+    rc, want = O.similarity_mh(seqs, 1, 200, seeds)
+    assert np.array_equal(a.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    b = device.similarity_mh(ds, 4, 200, seeds)
+    torch.cuda.synchronize()
+    assert device.mh_last_route()["sparse"]
+    monkeypatch.setenv("DYNAALIGN_MH_SPARSE_MAX_PAIRS", "10")
+    c = device.similarity_mh(ds, 4, 200, seeds)
+    torch.cuda.synchronize()
+    assert not device.mh_last_route()["sparse"]
+    monkeypatch.delenv("DYNAALIGN_MH_SPARSE_MAX_PAIRS")
+    monkeypatch.setenv("DYNAALIGN_MH_NO_SPARSE", "1")
+    d = device.similarity_mh(ds, 4, 200, seeds)
+    torch.cuda.synchronize()
+    assert not device.mh_last_route()["sparse"]
+    assert torch.equal(b.view(torch.int64), c.view(torch.int64)) and torch.equal(b.view(torch.int64), d.view(torch.int64))
