@@ -332,6 +332,21 @@ def main():
                 "note": "index expansion of the U x U count table to the dense f64 N x N; frac = SURVEY 8(d)'s algorithmic bytes per unordered pair "
                         "x the pairs of one launch / its HIP-event duration; frac_kernel_bytes counts the kernel's own 2 B read + 16 B written per pair"}
 
+    def stream_roofline(rows_ms, unique, wl_n=n):
+        """roofline object of k_expand_stream (ROW expansion of the unique strings' count table: the dominant kernel of the duplicate route): every
+        element of the dense f64 matrix written once -- 16-byte streaming stores from a table row held in LDS -- no gathered copy of the table"""
+        pairs_x = wl_n * (wl_n - 1) // 2                 # every unordered pair (both halves and the diagonal are written by this kernel)
+        bytes_alg = pairs_x * survey_bytes_per_pair(wl_n)
+        bytes_x = wl_n * wl_n * 8 + unique * ((unique + 7) // 8 * 8) * 2     # the result + the uint16 table read once (rows of strings with > 4 copies: once per 4)
+        t = rows_ms * 1e-3
+        traffic = pmc_traffic("k_expand_stream", wl_n)
+        return {"kernel": "k_expand_stream", "bound": "hbm", "achieved": bytes_alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_alg / t / 1e9 / HBM_PEAK_GBS, "frac_kernel_bytes": bytes_x / t / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                "avg_launch_ms": rows_ms, "algorithmic_bytes_per_launch": bytes_alg, "kernel_bytes_per_launch": bytes_x, "pairs_per_launch": pairs_x,
+                "note": "row expansion of the U x U count table to the dense f64 N x N (every element written once); frac = SURVEY 8(d)'s algorithmic bytes "
+                        "per unordered pair x all pairs / the kernel's HIP-event time; frac_kernel_bytes counts the result + the table read"}
+
     def sparse_roofline(tile_ms, incidences, wl_n=n):
         """roofline object of k_sp_tiles (the dominant kernel of the SPARSE route: inputs whose signatures rarely agree): it writes every
         element of the dense f64 matrix once from a 128 x 128 count image built in LDS out of the tile's bucket of matching incidences"""
@@ -400,8 +415,28 @@ def main():
         main_roof = sparse_roofline(phases["expand_ms"], route["sparse_pairs"])
     elif world == 1 and route["dedup"]:
         # the timed step ran on the table of unique strings: its dominant kernel is the expansion; K2 on U rows rides along
-        main_roof = expand_roofline(phases["expand_ms"])
-        main_roof["k2_on_unique"] = k2_roofline(phases["k2_ms"], state["bits"], route["unique"], 2)
+        rows_form = route.get("expansion", "").startswith("rows")
+        main_roof = stream_roofline(phases["expand_ms"], route["unique"]) if rows_form else expand_roofline(phases["expand_ms"])
+        if route.get("pipelined"):
+            # the table's compare runs on a side stream under the expansion (api.cpp "PIPELINED form"): k_expand_rows is launched once per chunk,
+            # on two alternating streams; expand_ms is the time SOME launch of it was running (union of the launches' HIP-event intervals)
+            el = max(1, route.get("expand_launches", 1))
+            main_roof["launches_per_step"] = el
+            main_roof["time_in_kernel_ms"] = main_roof["avg_launch_ms"]
+            main_roof["avg_launch_ms"] = main_roof["time_in_kernel_ms"] / el
+            for key in ("algorithmic_bytes_per_launch", "kernel_bytes_per_launch", "pairs_per_launch"):
+                main_roof[key.replace("_per_launch", "_per_step")] = main_roof[key]
+                main_roof[key] = main_roof[key] / el
+            if main_roof["traffic"] is not None:         # the PMC passes run the one-stream form (tools/prof_pmc.sh): one launch there = all launches here
+                main_roof["traffic_per_step"] = main_roof["traffic"]
+                main_roof["traffic"] = main_roof["traffic"] / el
+            main_roof["note"] += ("; PIPELINED: %d chunk launches per step (mean size reported per launch; frac = bytes of all launches / the time some launch was "
+                                  "running), co-running with the compare of the unique table (phases_ms.k2_ms = its span on the side stream: the first bands at "
+                                  "full occupancy, then one persistent workgroup per CU)%s: they overlap; "
+                                  "`one_stream` below is the same input with DYNAALIGN_MH_NO_PIPE=1 (each kernel alone)"
+                                  % (el, "" if rows_form else " and the column gathers (phases_ms.gather_ms = sum of the launches incl. their wait for LDS)"))
+        else:
+            main_roof["k2_on_unique"] = k2_roofline(phases["k2_ms"], state["bits"], route["unique"], 2)
     else:
         main_roof = k2_roofline(phases[k2_key], state["bits"])
     # the whole step against the roofline: SURVEY 8(d)'s bytes of ONE call (8.04e10 at N = 100k) / the step's wall time
@@ -425,9 +460,26 @@ def main():
         "phases_ms": phases,
     }
     if world == 1:
-        line["route"] = {"n": route["n"], "unique": route["unique"], "dedup": route["dedup"], "sparse": route.get("sparse", False), "plane_bits": route["plane_bits"],
-                         "note": "dedup: byte-identical sequences collapsed (exact) -- K1 / K1b / K2 on the unique strings, then column gather + "
-                                 "index expansion to the dense N x N; direct: the three kernels on all N rows"}
+        line["route"] = {"n": route["n"], "unique": route["unique"], "dedup": route["dedup"], "pipelined": route.get("pipelined", False),
+                         "expansion": route.get("expansion", ""), "chunks": route.get("chunks", 0), "sparse": route.get("sparse", False), "plane_bits": route["plane_bits"],
+                         "note": "dedup: byte-identical sequences collapsed (exact) -- K1 / K1b / K2 on the unique strings, then the index expansion to "
+                                 "the dense N x N (rows: k_expand_stream, one pass; tiles: column gather + k_expand_rows); direct: the three kernels on all N rows"}
+        if route.get("pipelined"):
+            os.environ["DYNAALIGN_MH_NO_PIPE"] = "1"             # the same route with the table finished before the expansion starts: every kernel alone
+            try:
+                odt, oevs = timed_steps(step, max(2, min(a.steps, 3)), 1)
+            finally:
+                del os.environ["DYNAALIGN_MH_NO_PIPE"]
+            osteps = max(2, min(a.steps, 3))
+            oph = phase_means(oevs)
+            oroof = stream_roofline(oph["expand_ms"], route["unique"]) if rows_form else expand_roofline(oph["expand_ms"])
+            oroof["k2_on_unique"] = k2_roofline(oph["k2_ms"], state["bits"], route["unique"], 2)
+            oroof["step_frac"] = step_bytes / (odt / osteps) / 1e9 / HBM_PEAK_GBS
+            main_roof["frac_one_stream"] = oroof["frac"]      # the same kernel by itself (one launch, nothing co-running), same process
+            main_roof["avg_launch_ms_one_stream"] = oph["expand_ms"]
+            line["one_stream"] = {"ms_per_step": odt / osteps * 1e3, "value": pairs_mh / (odt / osteps), "unit": "pairs/s", "steps": osteps,
+                                  "phases_ms": oph, "roofline": oroof,
+                                  "note": "DYNAALIGN_MH_NO_PIPE=1: K2 on the unique strings, then the expansion, one after the other on one stream"}
         if route["dedup"]:
             os.environ["DYNAALIGN_MH_NO_DEDUP"] = "1"            # the same input with the routes off: K2 on all N rows
             os.environ["DYNAALIGN_MH_NO_SPARSE"] = "1"

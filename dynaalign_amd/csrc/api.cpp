@@ -18,6 +18,7 @@
 #include <functional>
 #include <mutex>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -571,7 +572,39 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
 // otherwise (uniform peptides: nothing to collapse), or when the expansion's fast passes do not cover the shape
 // (U > 65536, n_hash > 2047, n < 2048), the direct kernels run.  Synchronises `stream` (K1b reads the dictionary sizes back).
 // DYNAALIGN_MH_NO_DEDUP=1 switches the route off.
-struct MhRoute { int64_t n = 0, unique = 0; int taken = 0, plane_bits = 0; float ms[6] = {0, 0, 0, 0, 0, 0}; };   // plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles
+// side stream + events of the pipelined form, pooled per device (creating them costs more than the route's small kernels)
+struct PipeRes { hipStream_t side = nullptr, alt[2] = {nullptr, nullptr}; std::vector<hipEvent_t> ev; int dev = 0; };
+struct PipePool { std::mutex m; std::vector<PipeRes *> idle[64]; };
+static PipePool &pipe_pool() { static PipePool *p = new PipePool; return *p; }   // never destroyed: the HIP runtime may be gone at exit
+static PipeRes *pipe_acquire(size_t events) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  PipeRes *r = nullptr;
+  {
+    std::lock_guard<std::mutex> g(pipe_pool().m);
+    auto &v = pipe_pool().idle[dev & 63];
+    if (!v.empty()) { r = v.back(); v.pop_back(); }
+  }
+  if (!r) {
+    r = new PipeRes;
+    r->dev = dev;
+    if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&r->alt[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&r->alt[1], hipStreamNonBlocking) != hipSuccess) { delete r; return nullptr; }
+  }
+  while (r->ev.size() < events) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) break;
+    r->ev.push_back(e);
+  }
+  if (r->ev.size() < events) { std::lock_guard<std::mutex> g(pipe_pool().m); pipe_pool().idle[dev & 63].push_back(r); return nullptr; }
+  return r;
+}
+static void pipe_release(PipeRes *r) {
+  if (!r) return;
+  std::lock_guard<std::mutex> g(pipe_pool().m);
+  pipe_pool().idle[r->dev & 63].push_back(r);
+}
+struct MhRoute { int64_t n = 0, unique = 0; int taken = 0, plane_bits = 0, chunks = 0, expand_launches = 0; float ms[6] = {0, 0, 0, 0, 0, 0}; };   // plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles
 static MhRoute &mh_route() { static thread_local MhRoute r; return r; }
 
 static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t n, int64_t total, int k, int n_hash,
@@ -592,6 +625,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   NwDedupPlan p{};
   int64_t U = n;
   bool take = false;
+  std::vector<int32_t> ub;
   if (eligible) {
     if ((rc = plan_work.alloc(nw_dedup_workspace_bytes(n, total))) != DA_OK) return rc;
     p = nw_dedup_layout(plan_work.p, n, total);
@@ -605,7 +639,18 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     // K2 on U rows + column gather + expansion (0.5 + 1.6 f + 22 f^2 + 4.1 f + 14.4 ms at N = 100k, f = U / n) against K1 + K1b + K2 with its
     // own float64 stores (27.2 ms): the route pays below f = 0.63
     take = U > 0 && U * 100 <= n * 60 && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
-    if (take && (rc = launch_nw_dedup_build(d_res, d_off, n, U, p, stream)) != DA_OK) return rc;
+    if (take && (rc = launch_nw_dedup_build(d_res, d_off, n, U, p, stream, true)) != DA_OK) return rc;   // ids by first occurrence
+    if (take) {
+      // ub[b] = unique ids the input rows [0, 1024 b) use (prefix counts of the plan, read at the band boundaries): the pipelined form's schedule
+      const int64_t NB = mh_sym_bands(n);
+      std::vector<int32_t> a((size_t)NB), b((size_t)NB);
+      DA_HIP_TRY(hipMemcpy2DAsync(a.data(), 4, p.pm, 4096, 4, (size_t)NB, hipMemcpyDeviceToHost, stream));
+      DA_HIP_TRY(hipMemcpy2DAsync(b.data(), 4, p.ps, 4096, 4, (size_t)NB, hipMemcpyDeviceToHost, stream));
+      DA_HIP_TRY(hipStreamSynchronize(stream));
+      ub.resize((size_t)NB + 1);
+      for (int64_t q = 0; q < NB; ++q) ub[(size_t)q] = a[(size_t)q] + b[(size_t)q];
+      ub[(size_t)NB] = (int32_t)U;
+    }
   }
   DA_HIP_TRY(hipEventRecord(ev[1], stream));
   const int64_t m = take ? U : n;                                   // rows the kernels see
@@ -657,7 +702,148 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   const int64_t ld_d = (U + 7) / 8 * 8;
   DevBuf dtab, ftab;
   if ((rc = dtab.alloc((size_t)U * (size_t)ld_d * 2)) != DA_OK) return rc;
+  // The expansion has two kernels families and each a pipelined form (DYNAALIGN_MH_EXPAND = rowspipe | rows | pipe | tiles; default: the first
+  // whose shape test passes; DYNAALIGN_MH_NO_PIPE=1 takes the pipelined forms out):
+  //   rows    K2 on the table, then k_expand_stream: every output row written once from its table row in LDS (no gathered copy)
+  //   tiles   K2, column gather (k_gather_columns), tile expansion (k_expand_rows) + diagonal / border tiles, one after the other
+  //   rowspipe / pipe   the same kernels with K2 run band by band on a side stream while finished table rows are expanded
+  const char *form_env = getenv("DYNAALIGN_MH_EXPAND");
+  const std::string form = form_env ? form_env : "";
+  const bool may_pipe = !getenv("DYNAALIGN_MH_NO_PIPE") && mh_compare_bands_ok(U, n_hash, bits, dtab.p, ld_d);
+  if ((form.empty() || form == "rows" || form == "rowspipe") && expand_stream_ok(n, U, n_hash, d_out, ld)) {
+    DevBuf lists;
+    if ((rc = lists.alloc(expand_stream_scratch_bytes(n, U))) != DA_OK) return rc;
+    if (form != "rows" && may_pipe) {
+      // the row expansion PIPELINED with K2: the first `head` bands of the table at full occupancy, the rest by the persistent kernel with `wg`
+      // workgroup(s) per CU on a side stream (one 36 KB ring fits beside the expansion's 94 KB row) while the finished table rows are expanded
+      const int64_t KB = mh_sym_bands(U);
+      int step = 4, wg = 1, head = 4;                              // (head 2-6 x step 3-6 measure within 0.3 ms of each other, profiles/r03_m_*)
+      if (const char *e = getenv("DYNAALIGN_MH_PIPE_STEP")) step = std::max(1, atoi(e));
+      if (const char *e = getenv("DYNAALIGN_MH_PIPE_WG")) wg = std::max(1, std::min(4, atoi(e)));
+      if (const char *e = getenv("DYNAALIGN_MH_PIPE_HEAD")) head = std::max(1, atoi(e));
+      const bool alt = !getenv("DYNAALIGN_MH_PIPE_ONE_STREAM");
+      std::vector<int64_t> cuts{0};
+      while (cuts.back() < KB) cuts.push_back(std::min(KB, cuts.back() + (cuts.size() == 1 ? head : step)));
+      const size_t C = cuts.size() - 1;
+      PipeRes *pr = pipe_acquire(3 * C + 1);
+      if (!pr) return fail(DA_ERR_HIP, "pipelined duplicate route: no side stream");
+      struct PipeGuard { PipeRes *r; ~PipeGuard() { (void)hipStreamSynchronize(r->side); (void)hipStreamSynchronize(r->alt[0]); (void)hipStreamSynchronize(r->alt[1]); pipe_release(r); } } pguard{pr};
+      hipEvent_t *pe = pr->ev.data();                                // per chunk: table rows done, rows begin / end; [3 C]: lists done
+      DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
+      if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, pr->side)) != DA_OK) return rc;
+      if ((rc = launch_expand_stream_lists(p.uidx, n, U, lists.p, stream)) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(pe[3 * C], stream));
+      if (alt) { DA_HIP_TRY(hipStreamWaitEvent(pr->alt[0], pe[3 * C], 0)); DA_HIP_TRY(hipStreamWaitEvent(pr->alt[1], pe[3 * C], 0)); }
+      for (size_t c = 0; c < C; ++c) {
+        if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, cuts[c], cuts[c + 1], c == 0 ? 4 : wg, pr->side)) != DA_OK) return rc;
+        DA_HIP_TRY(hipEventRecord(pe[3 * c], pr->side));
+        const hipStream_t es = alt ? pr->alt[c & 1] : stream;
+        DA_HIP_TRY(hipStreamWaitEvent(es, pe[3 * c], 0));
+        DA_HIP_TRY(hipEventRecord(pe[3 * c + 1], es));
+        if ((rc = launch_expand_stream_rows(dtab.as<uint16_t>(), ld_d, p.uidx, n, U, n_hash, d_out, ld, lists.p, cuts[c] * 1024, cuts[c + 1] * 1024, es)) != DA_OK) return rc;
+        DA_HIP_TRY(hipEventRecord(pe[3 * c + 2], es));
+      }
+      if (alt) for (size_t c = (C >= 2 ? C - 2 : 0); c < C; ++c) DA_HIP_TRY(hipStreamWaitEvent(stream, pe[3 * c + 2], 0));
+      DA_HIP_TRY(hipEventRecord(ev[5], stream));
+      DA_HIP_TRY(hipStreamSynchronize(stream));
+      route.taken = 5;
+      route.chunks = route.expand_launches = (int)C;
+      (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
+      (void)hipEventElapsedTime(&route.ms[1], ev[1], ev[2]);
+      (void)hipEventElapsedTime(&route.ms[2], ev[2], pe[3 * (C - 1)]);   // the compare's span on the side stream
+      (void)hipEventElapsedTime(&route.ms[3], ev[2], pe[3 * C]);          // the copy lists (beside the compare)
+      float covered_to = 0;
+      for (size_t c = 0; c < C; ++c) {                                    // ms[4]: the time some k_expand_stream launch was running (union)
+        float b = 0, e = 0;
+        (void)hipEventElapsedTime(&b, ev[2], pe[3 * c + 1]);
+        (void)hipEventElapsedTime(&e, ev[2], pe[3 * c + 2]);
+        if (e > covered_to) { route.ms[4] += e - std::max(b, covered_to); covered_to = e; }
+      }
+      return DA_OK;
+    }
+    if ((rc = launch_mh_compare(planes.as<uint32_t>(), U, n_hash, 0, U, true, DA_OUT_COMPACT, dtab.p, ld_d, stream, bits)) != DA_OK) return rc;
+    DA_HIP_TRY(hipEventRecord(ev[3], stream));
+    if ((rc = launch_expand_stream(dtab.as<uint16_t>(), ld_d, p.uidx, n, U, n_hash, d_out, ld, lists.p, stream, ev[4])) != DA_OK) return rc;
+    DA_HIP_TRY(hipEventRecord(ev[5], stream));
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+    route.taken = 4;
+    route.chunks = route.expand_launches = 1;
+    (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
+    (void)hipEventElapsedTime(&route.ms[1], ev[1], ev[2]);
+    (void)hipEventElapsedTime(&route.ms[2], ev[2], ev[3]);
+    (void)hipEventElapsedTime(&route.ms[3], ev[3], ev[4]);             // the copy lists (positions of every id, work items)
+    (void)hipEventElapsedTime(&route.ms[4], ev[4], ev[5]);             // k_expand_stream
+    return DA_OK;
+  }
   if ((rc = ftab.alloc(expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0))) != DA_OK) return rc;
+  if (form != "tiles" && !ub.empty() && may_pipe) {
+    // PIPELINED form.  The table is compared band by band (1024 unique rows each, in order) by the persistent kernel on
+    // a side stream with only `wg` workgroups per CU, so the rest of every CU stays free; the output row bands whose strings are all
+    // numbered below the finished table rows are gathered (on `stream`) and expanded (on two alternating streams: chunk c + 1 fills
+    // the CUs as chunk c drains) meanwhile.  The compare is VALU work, the expansion store work; unique ids are numbered by first
+    // occurrence, so both sweep their triangles in the same direction and the compare stays ahead.  Same kernels, same bits.
+    const int64_t KB = mh_sym_bands(U), NB = (int64_t)ub.size() - 1, ld_f = ceil_div(n, 8) * 8;
+    int step = 4, wg = 2;
+    if (const char *e = getenv("DYNAALIGN_MH_PIPE_STEP")) step = std::max(1, atoi(e));
+    if (const char *e = getenv("DYNAALIGN_MH_PIPE_WG")) wg = std::max(1, std::min(4, atoi(e)));
+    const bool alt = !getenv("DYNAALIGN_MH_PIPE_ONE_STREAM");
+    struct Chunk { int64_t kb0, kb1, ob0, ob1; };
+    std::vector<Chunk> chunks;
+    for (int64_t kb = 0, ob = 0; kb < KB;) {
+      const int64_t kb1 = std::min(KB, kb + (chunks.empty() ? 1 : step));   // a first chunk of one band: the expansion starts early
+      int64_t ob1 = ob;
+      if (kb1 == KB) ob1 = NB;
+      else while (ob1 < NB && (int64_t)ub[(size_t)ob1 + 1] <= kb1 * 1024) ++ob1;   // rows below 1024 (ob1 + 1) only use ids < ub[ob1 + 1]
+      chunks.push_back({kb, kb1, ob, ob1});
+      kb = kb1; ob = ob1;
+    }
+    const size_t C = chunks.size();
+    PipeRes *pr = pipe_acquire(5 * C);
+    if (!pr) return fail(DA_ERR_HIP, "pipelined duplicate route: no side stream");
+    // leaves the side streams idle before the buffers declared above go back to the cache (error returns included)
+    struct PipeGuard { PipeRes *r; ~PipeGuard() { (void)hipStreamSynchronize(r->side); (void)hipStreamSynchronize(r->alt[0]); (void)hipStreamSynchronize(r->alt[1]); pipe_release(r); } } pguard{pr};
+    hipEvent_t *pe = pr->ev.data();                                  // per chunk: table rows done, gather begin / end, rows begin / end
+    DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
+    if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, pr->side)) != DA_OK) return rc;
+    for (size_t c = 0; c < C; ++c) {
+      const Chunk &ch = chunks[c];
+      if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, ch.kb0, ch.kb1, wg, pr->side)) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(pe[5 * c], pr->side));
+      DA_HIP_TRY(hipStreamWaitEvent(stream, pe[5 * c], 0));
+      DA_HIP_TRY(hipEventRecord(pe[5 * c + 1], stream));
+      if ((rc = launch_gather_columns(dtab.as<uint16_t>(), ld_d, p.uidx, p.ufirst, n, U, ftab.as<uint16_t>(), ld_f, false, stream, 1, 0,
+                                      ch.kb0 * 1024, std::min(U, ch.kb1 * 1024))) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(pe[5 * c + 2], stream));
+      const hipStream_t es = alt ? pr->alt[c & 1] : stream;
+      if (alt) DA_HIP_TRY(hipStreamWaitEvent(es, pe[5 * c + 2], 0));
+      DA_HIP_TRY(hipEventRecord(pe[5 * c + 3], es));
+      if ((rc = launch_expand_rows(ftab.as<uint16_t>(), ld_f, p.uidx, n, false, n_hash, 0, d_out, ld, ch.ob0, ch.ob1, es)) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(pe[5 * c + 4], es));
+    }
+    if (alt) for (size_t c = (C >= 2 ? C - 2 : 0); c < C; ++c) DA_HIP_TRY(hipStreamWaitEvent(stream, pe[5 * c + 4], 0));
+    DA_HIP_TRY(hipEventRecord(ev[5], stream));
+    if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, DA_OUT_F64, false, n_hash, d_out, ld, stream, 0, ftab.as<uint16_t>(),
+                                   p.ufirst, U, nullptr, nullptr, 1, 0, true)) != DA_OK) return rc;
+    DA_HIP_TRY(hipEventRecord(ev[6], stream));
+    DA_HIP_TRY(hipStreamSynchronize(stream));
+    route.taken = 3;
+    route.chunks = (int)C;
+    for (const Chunk &ch : chunks) route.expand_launches += ch.ob1 > ch.ob0 ? 1 : 0;
+    (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
+    (void)hipEventElapsedTime(&route.ms[1], ev[1], ev[2]);
+    (void)hipEventElapsedTime(&route.ms[2], ev[2], pe[5 * (C - 1)]);       // the compare's span on the side stream (it overlaps what follows)
+    float covered_to = 0;                                                  // ms[4]: the time some k_expand_rows launch was running (their
+    for (size_t c = 0; c < C; ++c) {                                       // intervals overlap on the alternating streams: union, not sum)
+      float g = 0, b = 0, e = 0;
+      (void)hipEventElapsedTime(&g, pe[5 * c + 1], pe[5 * c + 2]);
+      (void)hipEventElapsedTime(&b, ev[2], pe[5 * c + 3]);
+      (void)hipEventElapsedTime(&e, ev[2], pe[5 * c + 4]);
+      route.ms[3] += g;                                                    // gathers: summed (each includes its wait for free LDS beside the expansion)
+      if (chunks[c].ob1 > chunks[c].ob0 && e > covered_to) { route.ms[4] += e - std::max(b, covered_to); covered_to = e; }
+    }
+    (void)hipEventElapsedTime(&route.ms[5], ev[5], ev[6]);
+    return DA_OK;
+  }
   if ((rc = launch_mh_compare(planes.as<uint32_t>(), U, n_hash, 0, U, true, DA_OUT_COMPACT, dtab.p, ld_d, stream, bits)) != DA_OK) return rc;
   DA_HIP_TRY(hipEventRecord(ev[3], stream));
   if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, DA_OUT_F64, false, n_hash, d_out, ld, stream, 0, ftab.as<uint16_t>(),
@@ -665,6 +851,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   DA_HIP_TRY(hipEventRecord(ev[6], stream));
   DA_HIP_TRY(hipStreamSynchronize(stream));                         // the buffers go back to the parked-buffer cache here
   route.taken = 1;
+  route.chunks = route.expand_launches = 1;
   (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
   (void)hipEventElapsedTime(&route.ms[1], ev[1], ev[2]);
   (void)hipEventElapsedTime(&route.ms[2], ev[2], ev[3]);
@@ -682,6 +869,13 @@ int da_dev_similarity_mh(const uint8_t *d_residues, const int64_t *d_offsets, in
   if (ld < n) return fail(DA_ERR_BAD_ARG, "ld (%lld) < n (%lld)", (long long)ld, (long long)n);
   if (n_hash > 65535) return fail(DA_ERR_UNSUPPORTED, "the compare kernel counts in 16 bits: n_hash <= 65535 (got %d); da_similarity_mh handles more", n_hash);
   return mh_full_symmetric(d_residues, d_offsets, n, total_residues, k, n_hash, d_seeds, d_out, ld, static_cast<hipStream_t>(stream));
+}
+
+int da_mh_last_route_chunks(int *chunks_out, int *expand_launches_out) {
+  const MhRoute &r = mh_route();
+  if (chunks_out) *chunks_out = r.chunks;
+  if (expand_launches_out) *expand_launches_out = r.expand_launches;
+  return DA_OK;
 }
 
 int da_mh_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, int *plane_bits_out, double *ms6_out) {

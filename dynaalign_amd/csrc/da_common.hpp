@@ -114,6 +114,13 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
                       void *d_out, int64_t ld, hipStream_t stream, int plane_bits = 32, int tile_stride = 1,
                       bool upper_only = false, int fold_q = 0, int64_t fold_w = 0);
+// the symmetric uint16 12-plane compare in pieces (pipelined duplicate route): tile-row bands of 8 x 128 rows, taken in order
+int64_t mh_sym_bands(int64_t n);
+int64_t mh_sym_band_prefix(int64_t n, int64_t band);
+bool mh_compare_bands_ok(int64_t n, int n_hash, int plane_bits, const void *d_out, int64_t ld);
+int launch_mh_compare_bands_u16(const uint32_t *d_planes, int64_t n, int n_hash, uint16_t *d_out, int64_t ld, int64_t band_begin,
+                                int64_t band_end, int wg_per_cu, hipStream_t stream);
+int launch_mh_compare_edges_u16(const uint32_t *d_planes, int64_t n, int n_hash, uint16_t *d_out, int64_t ld, hipStream_t stream);
 // minhash_kernels.hip, SPARSE route of the symmetric float64 compare (inputs whose signatures rarely agree): see the kernels' header comment
 size_t mh_sparse_pairs_limit();
 int launch_mh_sparse_count(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, unsigned long long *d_stats, hipStream_t stream);
@@ -163,12 +170,24 @@ struct NwDedupPlan {
 NwDedupPlan nw_dedup_layout(void *work, int64_t n, int64_t total);
 size_t nw_dedup_workspace_bytes(int64_t n, int64_t total);
 int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t n, const NwDedupPlan &p, hipStream_t stream);
-int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t U, const NwDedupPlan &p, hipStream_t stream);
+int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t U, const NwDedupPlan &p, hipStream_t stream,
+                          bool first_order = false);   // true: unique ids purely by first occurrence (default: multi-copy strings first)
 // minhash_kernels.hip: out[i][j] = value(D[uidx[min(i,j)]][uidx[max(i,j)]]) for the dense symmetric n x n result
 int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
                          void *d_out, int64_t ld, hipStream_t stream, int nw_max_len = 0, uint16_t *d_F = nullptr,
                          const int32_t *d_ufirst = nullptr, int64_t U = 0, hipEvent_t after_gather = nullptr, hipEvent_t after_rows = nullptr,
-                         int table_world = 1, int64_t table_rows_local = 0);   // table_world > 1: d_D is all-gathered row blocks of cyclic 128-row units
+                         int table_world = 1, int64_t table_rows_local = 0,    // table_world > 1: d_D is all-gathered row blocks of cyclic 128-row units
+                         bool only_leftover = false);                          // true: the caller ran launch_gather_columns / launch_expand_rows itself
+// ROW expansion (MinHash: symmetric table): every output row written once from its table row held in LDS; no gathered copy
+bool expand_stream_ok(int64_t n, int64_t U, int n_hash, const void *d_out, int64_t ld);
+size_t expand_stream_scratch_bytes(int64_t n, int64_t U);
+int launch_expand_stream(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int64_t U, int n_hash, double *d_out, int64_t ld,
+                         void *d_scratch, hipStream_t stream, hipEvent_t after_lists = nullptr);
+int launch_expand_stream_lists(const int32_t *d_uidx, int64_t n, int64_t U, void *d_scratch, hipStream_t stream);
+int launch_expand_stream_rows(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int64_t U, int n_hash, double *d_out, int64_t ld,
+                              void *d_scratch, int64_t row_begin, int64_t row_end, hipStream_t stream);
+int launch_expand_rows(const uint16_t *d_F, int64_t ld_f, const int32_t *d_uidx, int64_t n, bool is_nw, int n_hash, int nw_max_len,
+                       double *d_out, int64_t ld, int64_t band_begin, int64_t band_end, hipStream_t stream);
 // bytes of the column-gathered table (d_F) that switches launch_expand_unique to its two streaming passes; 0 = shape not covered
 size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, int n_hash, int nw_max_len);
 int launch_upper_histogram(const uint16_t *d_m, int64_t ld, int64_t n, int nbins, unsigned long long *d_hist,
@@ -180,7 +199,7 @@ int launch_extract_edges(const uint16_t *d_m, int64_t ld, int64_t n, const uint8
 // minhash_kernels.hip: F[r][j] = D[r][uidx[j]] for the columns right of (from_first_tile: from) the 128-tile of r's first occurrence
 int launch_gather_columns(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, const int32_t *d_ufirst, int64_t n, int64_t U,
                           uint16_t *d_F, int64_t ld_f, bool from_first_tile, hipStream_t stream, int table_world = 1,
-                          int64_t table_rows_local = 0);
+                          int64_t table_rows_local = 0, int64_t row_begin = 0, int64_t row_end = -1);
 // graph_kernels.hip: (i <= j, code) edge list -> symmetric CSR sorted by (row, column); diagonal entries -> loops[] (0xFFFF = none)
 size_t edges_to_csr_workspace_bytes(int64_t m, int64_t n);
 int launch_edges_to_csr(const int32_t *d_i, const int32_t *d_j, const uint16_t *d_v, int64_t m, int64_t n, void *d_work, size_t work_bytes,

@@ -593,7 +593,8 @@ constexpr int K2_P12_TABLE = 512;
 template <bool F64>
 __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
                                                                   void *__restrict__ out_v, int64_t ld, int64_t ntiles,
-                                                                  int64_t per_xcd, int wg_per_xcd) {
+                                                                  int64_t per_xcd, int wg_per_xcd, int64_t tile_begin) {
+  // the tile ids [tile_begin, ntiles) are dealt in 8 runs of per_xcd (the pipelined duplicate route launches one band range at a time)
   constexpr int PL = 12, SEGS = 3, STAGE_UNITS = 2 * K2_TILE * SEGS;
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring
   __shared__ double ratio_tab[F64 ? K2_P12_TABLE : 1];
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
   // tile ids fit 31 bits (the launcher checks): 32-bit scalars, so that loop control stays on the scalar unit -- nothing
   // wave-uniform may end up in a VGPR that has to live across the block (it clobbers the VGPR file; hipcc would spill to
   // scratch and reload behind a vmcnt wait in the middle of the tile's stores)
-  const int lim = (int)(((int64_t)(xcd + 1) * per_xcd < ntiles) ? (int64_t)(xcd + 1) * per_xcd : ntiles);
+  const int lim = (int)((tile_begin + (int64_t)(xcd + 1) * per_xcd < ntiles) ? tile_begin + (int64_t)(xcd + 1) * per_xcd : ntiles);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (F64) {
     for (int c = tid; c <= n_hash; c += K2_THREADS) ratio_tab[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
     for (;;) {
       if (tid == 0) s_next[fetch_no & 1] = atomicAdd(&g_k2_next[xcd], 1u);
       __syncthreads();
-      const int Lq = (int)((int64_t)xcd * per_xcd) + (int)__builtin_amdgcn_readfirstlane(s_next[fetch_no & 1]);
+      const int Lq = (int)(tile_begin + (int64_t)xcd * per_xcd) + (int)__builtin_amdgcn_readfirstlane(s_next[fetch_no & 1]);
       ++fetch_no;
       if (Lq >= lim) return lim;
       int To = T;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
   };
   int L = next_dyn(cur);
 #else
-  int L = next_taken((int)((int64_t)xcd * per_xcd) + slot, cur);
+  int L = next_taken((int)(tile_begin + (int64_t)xcd * per_xcd) + slot, cur);
 #endif
   uint32_t flags = 1u, phase = 0u;                             // bit 0: first tile of this workgroup; ring slot of the tile's stage 0
 #ifdef DA_K2_TIMING
@@ -1932,9 +1933,9 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
     }
 #endif
     if (kind == DA_OUT_F64)
-      hipLaunchKernelGGL(k_mh_compare_p12<true>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd);
+      hipLaunchKernelGGL(k_mh_compare_p12<true>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd, (int64_t)0);
     else
-      hipLaunchKernelGGL(k_mh_compare_p12<false>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd);
+      hipLaunchKernelGGL(k_mh_compare_p12<false>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd, (int64_t)0);
   } else if (a12) {
     // float64, OPT-IN experiments of round 3 (both bit-exact and tested; neither beats one tile per workgroup on MI355X):
     // DYNAALIGN_K2_INLOOP=1: the persistent kernel whose stores ride inside the next tile's stage loop (k_mh_compare_q12; 16 / 8 / 4
@@ -1976,6 +1977,56 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   }
 #undef DA_K2_PL
 #undef DA_K2
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+// ---- the symmetric uint16 12-plane compare in pieces (pipelined duplicate route, api.cpp) --------------------------------
+// decode_tile numbers the symmetric tiles band by band (K2_BAND tile rows, every tile right of the diagonal), so the tile rows
+// [8 b0, 8 b1) are the id range [prefix(b0), prefix(b1)) and, bands taken in order, the table rows of band b are complete (direct
+// and mirrored stores) once the bands <= b have run.
+int64_t mh_sym_band_prefix(int64_t n, int64_t band) {
+  const int64_t T = ceil_div(n, K2_TILE), S = K2_BAND, nfull = T / S;
+  if (band <= 0) return 0;
+  if (band > nfull) return T * (T + 1) / 2;
+  const int64_t c0 = S * (S + 1) / 2 + (T - S) * S;
+  return band * c0 - (S * S / 2) * band * (band - 1);
+}
+int64_t mh_sym_bands(int64_t n) { return ceil_div(ceil_div(n, K2_TILE), K2_BAND); }
+bool mh_compare_bands_ok(int64_t n, int n_hash, int plane_bits, const void *d_out, int64_t ld) {
+  const int64_t T = ceil_div(n, K2_TILE);
+  return plane_bits == 12 && n_hash > K2_GROUP && n_hash <= 65535 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+         (reinterpret_cast<uintptr_t>(d_out) & 3) == 0 && T * (T + 1) / 2 < 0x7fffffffLL;
+}
+// interior tiles of the bands [band_begin, band_end) by the persistent kernel with at most wg_per_cu resident workgroups per CU:
+// a grid that small leaves the rest of every CU to kernels of other streams (the expansion's stores)
+int launch_mh_compare_bands_u16(const uint32_t *d_planes, int64_t n, int n_hash, uint16_t *d_out, int64_t ld, int64_t band_begin,
+                                int64_t band_end, int wg_per_cu, hipStream_t stream) {
+  if (!mh_compare_bands_ok(n, n_hash, 12, d_out, ld)) return fail(DA_ERR_UNSUPPORTED, "banded compare: shape not covered");
+  const int64_t t0 = mh_sym_band_prefix(n, band_begin), t1 = mh_sym_band_prefix(n, band_end);
+  if (t1 <= t0) return DA_OK;
+  static std::atomic<int> cus_cache;
+  if (!cus_cache.load()) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    DA_HIP_TRY(hipGetDevice(&dev));
+    DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    cus_cache.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+  }
+  const int64_t per_xcd = ceil_div(t1 - t0, 8);
+  int wg_per_xcd = std::max(1, std::min(wg_per_cu, 4)) * ((cus_cache.load() + 7) / 8);
+  if ((int64_t)wg_per_xcd > per_xcd) wg_per_xcd = (int)per_xcd;
+  hipLaunchKernelGGL(k_mh_compare_p12<false>, dim3((unsigned)(8 * wg_per_xcd)), dim3(K2_THREADS), 0, stream, d_planes, n, n_hash,
+                     static_cast<void *>(d_out), ld, t1, per_xcd, wg_per_xcd, t0);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+// the tiles the kernel above leaves everywhere: diagonal tiles and the last tile column (with their mirrors)
+int launch_mh_compare_edges_u16(const uint32_t *d_planes, int64_t n, int n_hash, uint16_t *d_out, int64_t ld, hipStream_t stream) {
+  const int T = (int)ceil_div(n, K2_TILE);
+  const int64_t ntiles = count_tiles(T, T, true);
+  hipLaunchKernelGGL((k_mh_compare<true, false, 12>), dim3((unsigned)(2 * (int64_t)T - 1)), dim3(K2_THREADS), 0, stream, d_planes, n, n_hash,
+                     (int64_t)0, n, 1, 0, T, static_cast<void *>(d_out), ld, ntiles, ceil_div(ntiles, 8), 0, (int64_t)0, K2_BAND, 1);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
@@ -2280,8 +2331,8 @@ constexpr int GC_THREADS = 1024;
 // registers while the current one is gathered out of LDS (U <= 65536 -> at most 8 16-byte units per thread)
 __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                                const int32_t *__restrict__ ufirst, int n, int U, uint16_t *__restrict__ F,
-                                                               int64_t ld_f, TableRows trows, int from_first_tile) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t gc_row[];   // ld_d entries
+                                                               int64_t ld_f, TableRows trows, int from_first_tile, int row_begin) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t gc_row[];   // ld_d entries; the rows [row_begin, U) are gathered
   const int units = (int)(ld_d >> 3);
   uint4 pre[8];
 #define GC_FETCH(row)                                                                                   \
@@ -2292,7 +2343,7 @@ __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *_
       pre[q] = u < units ? src_[u] : make_uint4(0, 0, 0, 0);                                            \
     }                                                                                                   \
   }
-  int r = blockIdx.x;
+  int r = row_begin + (int)blockIdx.x;
   if (r < U) GC_FETCH(r)
   const int2 *u2 = reinterpret_cast<const int2 *>(uidx);
   const int j2_end = n >> 1;                                         // column pairs; an odd last column is written by itself below
@@ -2320,11 +2371,11 @@ __global__ __launch_bounds__(GC_THREADS) void k_gather_columns(const uint16_t *_
 template <bool IS_NW>
 __global__ __launch_bounds__(256, 4) void k_expand_rows(const uint16_t *__restrict__ F, int64_t ld_f, const int32_t *__restrict__ uidx,
                                                         int n, int n_hash, int tab_stride, int tab_entries, double *__restrict__ out,
-                                                        int64_t ld, int T128, int64_t ntiles, int64_t per_xcd) {
+                                                        int64_t ld, int T128, int64_t ntiles, int64_t per_xcd, int64_t tile_begin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char er_lds[];   // 128 x ER_STRIDE tile, then the value table
   double *tab = reinterpret_cast<double *>(er_lds + 128 * ER_STRIDE);
-  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (L >= ntiles) return;
+  const int64_t L = tile_begin + (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the ids [tile_begin, ntiles) in 8 runs
+  if (L >= ntiles || L >= tile_begin + (int64_t)((blockIdx.x & 7) + 1) * per_xcd) return;
   const TileId tt = decode_tile(L, T128, T128, true);
   if (!tt.valid || !expand_fast_takes(tt.ti, tt.tj, n, ld, out)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -2356,6 +2407,195 @@ __global__ __launch_bounds__(256, 4) void k_expand_rows(const uint16_t *__restri
   er_store_tile(er_lds, widen, out, ld, I0, J0, tx, ty);
 }
 
+// ---- ROW expansion: the N x N float64 matrix straight from the U x U count table, no gathered copy (round 3) -----------------
+// k_gather_columns + k_expand_rows move the table twice more (9 GB written, 9 GB read) and the tiles' LDS images keep the gather out of
+// the CUs.  Here one workgroup holds row r of the (symmetric) table in LDS -- like the gather -- and writes the OUTPUT rows of r's copies
+// itself: for every column pair (j, j + 1) the two counts D[r][u(j)], D[r][u(j + 1)] come out of LDS, go through the count -> double table
+// (also LDS, built with the reference's divide) and leave as one 16-byte streaming store per copy of r.  Every element of the result is
+// written exactly once (diagonal and borders included: no second kernel), a wave-instruction covers 1 KiB of one output row, and the
+// only global reads are the table rows (4 GB) and the id map (L2-resident).  Work items are (unique row, up to ES_COPIES of its copies),
+// listed by k_es_items so that a string with thousands of copies is spread over many workgroups.
+constexpr int ES_THREADS = 1024, ES_COPIES = 4;
+__global__ __launch_bounds__(256) void k_es_count(const int32_t *__restrict__ uidx, int n, uint32_t *__restrict__ cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(&cnt[uidx[i]], 1u);
+}
+// exclusive scans of cnt[] (-> cstart: where the positions of id u start) and of ceil(cnt / ES_COPIES) (-> istart: its work items), one
+// workgroup, both sums in the halves of a 64-bit word; cstart[U] = n, istart[U] = number of items
+__global__ __launch_bounds__(1024) void k_es_scan(const uint32_t *__restrict__ cnt, int U, uint32_t *__restrict__ cstart, uint32_t *__restrict__ istart) {
+  __shared__ uint64_t wsum[16];
+  __shared__ uint64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < U; base += 1024) {
+    const int u = base + tid;
+    const uint32_t c = u < U ? cnt[u] : 0u;
+    const uint64_t v = (uint64_t)c | ((uint64_t)((c + ES_COPIES - 1) / ES_COPIES) << 32);
+    uint64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint64_t carry = carry_s;
+    if (u < U) {
+      const uint64_t e = carry + woff + x - v;
+      cstart[u] = (uint32_t)e;
+      istart[u] = (uint32_t)(e >> 32);
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) { cstart[U] = (uint32_t)carry_s; istart[U] = (uint32_t)(carry_s >> 32); }
+}
+// positions of every id's copies (any order inside an id: the copies receive identical values) and the item list
+__global__ __launch_bounds__(256) void k_es_fill(const int32_t *__restrict__ uidx, int n, int U, const uint32_t *__restrict__ cstart,
+                                                 const uint32_t *__restrict__ istart, uint32_t *__restrict__ cursor, int32_t *__restrict__ cpos,
+                                                 int2 *__restrict__ items) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int u = uidx[i];
+    cpos[cstart[u] + atomicAdd(&cursor[u], 1u)] = i;
+  }
+  if (i < U) {
+    const uint32_t first = istart[i], cnt = istart[i + 1] - first;
+    for (uint32_t q = 0; q < cnt; ++q) items[first + q] = make_int2(i, (int)(q * ES_COPIES));
+  }
+}
+__global__ __launch_bounds__(ES_THREADS) void k_expand_stream(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
+                                                              const uint32_t *__restrict__ cstart, const int32_t *__restrict__ cpos,
+                                                              const int2 *__restrict__ items, const uint32_t *__restrict__ istart, int row_begin,
+                                                              int row_end, int n, int n_hash, double *__restrict__ out, int64_t ld) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char es_lds[];   // count -> double table (n_hash + 1 entries, padded to 16 B), then the table row
+  double *tab = reinterpret_cast<double *>(es_lds);
+  const int tab_bytes = ((n_hash + 1) * 8 + 15) & ~15;
+  uint16_t *row = reinterpret_cast<uint16_t *>(es_lds + tab_bytes);
+  const int tid = threadIdx.x;
+  for (int e = tid; e <= n_hash; e += ES_THREADS) tab[e] = (double)e / (double)n_hash;              // src/minHash.cpp:174
+  const int n_items = (int)istart[row_end];                          // the items of the table rows [row_begin, row_end)
+  const int units = (int)(ld_d >> 3);
+  uint4 pre[8];
+#define ES_FETCH(r_)                                                                                    \
+  {                                                                                                     \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(D + (int64_t)(r_) * ld_d);                      \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                     \
+      const int u = tid + q * ES_THREADS;                                                               \
+      pre[q] = u < units ? src_[u] : make_uint4(0, 0, 0, 0);                                            \
+    }                                                                                                   \
+  }
+  int k = (int)istart[row_begin] + (int)blockIdx.x;
+  int2 it = k < n_items ? items[k] : make_int2(0, 0);
+  if (k < n_items) ES_FETCH(it.x)
+  const int2 *u2 = reinterpret_cast<const int2 *>(uidx);
+  const int j2_end = n >> 1;
+  for (; k < n_items; k += gridDim.x) {
+    __syncthreads();                                                 // the previous item's reads have left the LDS row (and the table is built)
+    uint4 *dst = reinterpret_cast<uint4 *>(row);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int u = tid + q * ES_THREADS;
+      if (u < units) dst[u] = pre[q];
+    }
+    __syncthreads();
+    // this item's output rows (wave-uniform), then the next item's table row on its way while this one is expanded
+    const uint32_t c0 = cstart[it.x] + (uint32_t)it.y, c_end = cstart[it.x + 1];
+    const int ncop = (int)min((uint32_t)ES_COPIES, c_end - c0);
+    double *orow[ES_COPIES];
+#pragma unroll
+    for (int q = 0; q < ES_COPIES; ++q) orow[q] = out + (int64_t)cpos[c0 + (uint32_t)min(q, ncop - 1)] * ld;
+    const int kn = k + (int)gridDim.x;
+    int2 itn = make_int2(0, 0);
+    if (kn < n_items) { itn = items[kn]; ES_FETCH(itn.x) }
+#pragma unroll 4
+    for (int j2 = tid; j2 < j2_end; j2 += ES_THREADS) {
+      const int2 c = u2[j2];
+      const double v0 = tab[row[c.x]], v1 = tab[row[c.y]];
+      nt_store2(orow[0] + 2 * j2, v0, v1);
+      if (ncop > 1) nt_store2(orow[1] + 2 * j2, v0, v1);
+      if (ncop > 2) nt_store2(orow[2] + 2 * j2, v0, v1);
+      if (ncop > 3) nt_store2(orow[3] + 2 * j2, v0, v1);
+    }
+    if ((n & 1) && tid == 0) {                                       // odd n: the last column
+      const double v = tab[row[uidx[n - 1]]];
+      for (int q = 0; q < ncop; ++q) orow[q][n - 1] = v;
+    }
+    it = itn;
+  }
+#undef ES_FETCH
+}
+
+bool expand_stream_ok(int64_t n, int64_t U, int n_hash, const void *d_out, int64_t ld) {
+  return n >= 2 && n <= 0x7fffffffLL && U >= 1 && U <= 65536 && n_hash >= 1 && n_hash <= 2047 && (ld & 1) == 0 &&
+         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && !getenv("DYNAALIGN_EXPAND_NO_STREAM");
+}
+size_t expand_stream_scratch_bytes(int64_t n, int64_t U) {
+  // cnt[U] + cursor[U] (zeroed together), cstart[U + 1], istart[U + 1], cpos[n], items[U + n / ES_COPIES + 1]
+  return ((size_t)(4 * U + 8) * 4 + (size_t)n * 4 + (size_t)(U + n / ES_COPIES + 2) * 8 + 1024);
+}
+struct EsLists { uint32_t *cnt, *cursor, *cstart, *istart; int32_t *cpos; int2 *items; };
+static EsLists es_layout(void *d_scratch, int64_t n, int64_t U) {
+  uint32_t *w = static_cast<uint32_t *>(d_scratch);
+  EsLists L;
+  L.cnt = w; L.cursor = w + U; L.cstart = w + 2 * U; L.istart = L.cstart + (U + 1);
+  L.cpos = reinterpret_cast<int32_t *>(L.istart + (U + 1));
+  L.items = reinterpret_cast<int2 *>((reinterpret_cast<uintptr_t>(L.cpos + n) + 15) & ~(uintptr_t)15);
+  return L;
+}
+// the copy lists of the row expansion (positions of every unique id's copies, work items), stream-ordered
+int launch_expand_stream_lists(const int32_t *d_uidx, int64_t n, int64_t U, void *d_scratch, hipStream_t stream) {
+  const EsLists L = es_layout(d_scratch, n, U);
+  DA_HIP_TRY(hipMemsetAsync(L.cnt, 0, (size_t)U * 8, stream));
+  const unsigned nb = (unsigned)ceil_div(std::max(n, U), 256);
+  hipLaunchKernelGGL(k_es_count, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, d_uidx, (int)n, L.cnt);
+  hipLaunchKernelGGL(k_es_scan, dim3(1), dim3(1024), 0, stream, L.cnt, (int)U, L.cstart, L.istart);
+  hipLaunchKernelGGL(k_es_fill, dim3(nb), dim3(256), 0, stream, d_uidx, (int)n, (int)U, L.cstart, L.istart, L.cursor, L.cpos, L.items);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+// k_expand_stream on the table rows [row_begin, row_end) (lists from launch_expand_stream_lists on the same scratch)
+int launch_expand_stream_rows(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int64_t U, int n_hash, double *d_out, int64_t ld,
+                              void *d_scratch, int64_t row_begin, int64_t row_end, hipStream_t stream) {
+  if (!expand_stream_ok(n, U, n_hash, d_out, ld) || (ld_d & 7) || ld_d > 65536 || (reinterpret_cast<uintptr_t>(d_D) & 15))
+    return fail(DA_ERR_UNSUPPORTED, "row expansion: shape not covered");
+  if (row_end > U) row_end = U;
+  if (row_begin >= row_end) return DA_OK;
+  const EsLists L = es_layout(d_scratch, n, U);
+  static std::atomic<int> es_cus;
+  static std::atomic<uint64_t> es_attr_done;
+  int dev = 0;
+  DA_HIP_TRY(hipGetDevice(&dev));
+  if (!((es_attr_done.load() >> (dev & 63)) & 1u)) {
+    hipDeviceProp_t prop;
+    DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2 + 2048 * 8));
+    es_cus.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    es_attr_done.fetch_or(1ull << (dev & 63));
+  }
+  const size_t lds = (size_t)(((n_hash + 1) * 8 + 15) & ~15) + (size_t)ld_d * 2;
+  const int wg_per_cu = lds <= 76 * 1024 ? 2 : 1;                      // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
+  int64_t grid = (int64_t)es_cus.load() * wg_per_cu;
+  if (const char *e = getenv("DYNAALIGN_EXPAND_STREAM_GRID")) grid = std::max(1, atoi(e));
+  grid = std::min<int64_t>(grid, (row_end - row_begin) + n / ES_COPIES + 1);
+  hipLaunchKernelGGL(k_expand_stream, dim3((unsigned)grid), dim3(ES_THREADS), lds, stream, d_D, ld_d, d_uidx, L.cstart, L.cpos, L.items, L.istart,
+                     (int)row_begin, (int)row_end, (int)n, n_hash, d_out, ld);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+int launch_expand_stream(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int64_t U, int n_hash, double *d_out, int64_t ld,
+                         void *d_scratch, hipStream_t stream, hipEvent_t after_lists) {
+  if (!expand_stream_ok(n, U, n_hash, d_out, ld)) return fail(DA_ERR_UNSUPPORTED, "row expansion: shape not covered");
+  int rc = launch_expand_stream_lists(d_uidx, n, U, d_scratch, stream);
+  if (rc != DA_OK) return rc;
+  if (after_lists) DA_HIP_TRY(hipEventRecord(after_lists, stream));
+  return launch_expand_stream_rows(d_D, ld_d, d_uidx, n, U, n_hash, d_out, ld, d_scratch, 0, U, stream);
+}
+
 // device bytes of the column-gathered table the two-pass expansion wants (0: the shape is not covered, pass NULL)
 size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, int n_hash, int nw_max_len) {
   if (kind != DA_OUT_F64 || n < 256 || U > 65536 || U < 1 || getenv("DYNAALIGN_EXPAND_NO_FAST")) return 0;
@@ -2364,7 +2604,11 @@ size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, i
 }
 
 int launch_gather_columns(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, const int32_t *d_ufirst, int64_t n, int64_t U,
-                          uint16_t *d_F, int64_t ld_f, bool from_first_tile, hipStream_t stream, int table_world, int64_t table_rows_local) {
+                          uint16_t *d_F, int64_t ld_f, bool from_first_tile, hipStream_t stream, int table_world, int64_t table_rows_local,
+                          int64_t row_begin, int64_t row_end) {
+  if (row_end < 0 || row_end > U) row_end = U;                         // the unique rows [row_begin, row_end): everything by default
+  if (row_begin < 0) row_begin = 0;
+  if (U >= 1 && row_begin >= row_end) return DA_OK;
   if (U < 1 || U > 65536 || (ld_d & 7) || ld_d > 65536 || (reinterpret_cast<uintptr_t>(d_D) & 15) || (ld_f & 1))
     return fail(DA_ERR_UNSUPPORTED, "column gather: at most 65536 unique strings, 16-byte aligned table rows");
   const TableRows trows{table_world, table_rows_local};
@@ -2381,16 +2625,36 @@ int launch_gather_columns(const uint16_t *d_D, int64_t ld_d, const int32_t *d_ui
     gc_attr_done.fetch_or(1ull << (dev & 63));
   }
   const int gc_wg = row_bytes <= 40 * 1024 ? 2 : 1;                    // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
-  const int64_t gc_grid = std::min<int64_t>(U, (int64_t)gc_cus.load() * gc_wg);
+  const int64_t gc_grid = std::min<int64_t>(row_end - row_begin, (int64_t)gc_cus.load() * gc_wg);
   hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)gc_grid), dim3(GC_THREADS), row_bytes, stream, d_D, ld_d, d_uidx, d_ufirst, (int)n,
-                     (int)U, d_F, ld_f, trows, from_first_tile ? 1 : 0);
+                     (int)row_end, d_F, ld_f, trows, from_first_tile ? 1 : 0, (int)row_begin);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+
+// k_expand_rows on the output tile-row bands [band_begin, band_end) (8 x 128 rows each, decode_tile's numbering of the n x n tiles);
+// band_end < 0: all of them
+int launch_expand_rows(const uint16_t *d_F, int64_t ld_f, const int32_t *d_uidx, int64_t n, bool is_nw, int n_hash, int nw_max_len,
+                       double *d_out, int64_t ld, int64_t band_begin, int64_t band_end, hipStream_t stream) {
+  const int T128 = (int)ceil_div(n, 128);
+  if (band_end < 0) band_end = mh_sym_bands(n);
+  const int64_t t0 = mh_sym_band_prefix(n, band_begin), t1 = mh_sym_band_prefix(n, band_end);
+  if (t1 <= t0) return DA_OK;
+  const int64_t px = ceil_div(t1 - t0, 8);
+  const int stride = is_nw ? 2 * nw_max_len + 1 : 1;
+  const int entries = is_nw ? (nw_max_len + 1) * stride : n_hash + 1;
+  const size_t lds = 128 * ER_STRIDE + (size_t)entries * 8;
+  if (is_nw) hipLaunchKernelGGL(k_expand_rows<true>, dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_F, ld_f, d_uidx, (int)n, n_hash,
+                                stride, entries, d_out, ld, T128, t1, px, t0);
+  else hipLaunchKernelGGL(k_expand_rows<false>, dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_F, ld_f, d_uidx, (int)n, n_hash,
+                          stride, entries, d_out, ld, T128, t1, px, t0);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
 
 int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int kind, bool is_nw, int n_hash,
                          void *d_out, int64_t ld, hipStream_t stream, int nw_max_len, uint16_t *d_F, const int32_t *d_ufirst, int64_t U,
-                         hipEvent_t after_gather, hipEvent_t after_rows, int table_world, int64_t table_rows_local) {
+                         hipEvent_t after_gather, hipEvent_t after_rows, int table_world, int64_t table_rows_local, bool only_leftover) {
   const TableRows trows{table_world, table_rows_local};
   if (n <= 0) return DA_OK;
   if (n > 0x7fffffffLL) return fail(DA_ERR_UNSUPPORTED, "expand: matrix too large");
@@ -2404,20 +2668,14 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   // the rest (diagonal, borders) by the 64 x 64 kernel below
   const bool fast = d_F != nullptr && expand_rows_workspace_bytes(n, U, kind, is_nw, n_hash, nw_max_len) != 0 && (ld & 1) == 0 &&
                     (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
-  if (fast) {
+  if (only_leftover && !fast) return fail(DA_ERR_BAD_ARG, "expand: the streaming passes do not cover this shape");
+  if (fast && !only_leftover) {
     const int64_t ld_f = ceil_div(n, 8) * 8;
     int rc_g = launch_gather_columns(d_D, ld_d, d_uidx, d_ufirst, n, U, d_F, ld_f, false, stream, table_world, table_rows_local);
     if (rc_g != DA_OK) return rc_g;
     if (after_gather) DA_HIP_TRY(hipEventRecord(after_gather, stream));
-    const int T128 = (int)ceil_div(n, 128);
-    const int64_t t128 = (int64_t)T128 * (T128 + 1) / 2, px = ceil_div(t128, 8);
-    const int stride = is_nw ? 2 * nw_max_len + 1 : 1;
-    const int entries = is_nw ? (nw_max_len + 1) * stride : n_hash + 1;
-    const size_t lds = 128 * ER_STRIDE + (size_t)entries * 8;
-    if (is_nw) hipLaunchKernelGGL(k_expand_rows<true>, dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_F, ld_f, d_uidx, (int)n, n_hash,
-                                  stride, entries, static_cast<double *>(d_out), ld, T128, t128, px);
-    else hipLaunchKernelGGL(k_expand_rows<false>, dim3((unsigned)(px * 8)), dim3(256), lds, stream, d_F, ld_f, d_uidx, (int)n, n_hash,
-                            stride, entries, static_cast<double *>(d_out), ld, T128, t128, px);
+    rc_g = launch_expand_rows(d_F, ld_f, d_uidx, n, is_nw, n_hash, nw_max_len, static_cast<double *>(d_out), ld, 0, -1, stream);
+    if (rc_g != DA_OK) return rc_g;
   }
   else if (after_gather) DA_HIP_TRY(hipEventRecord(after_gather, stream));
   if (after_rows) DA_HIP_TRY(hipEventRecord(after_rows, stream));

@@ -938,11 +938,12 @@ __global__ __launch_bounds__(256) void k_dd_assign(const int32_t *__restrict__ r
                                                    const int32_t *__restrict__ last, const int32_t *__restrict__ pm,
                                                    const int32_t *__restrict__ ps, const int64_t *__restrict__ off, int32_t n,
                                                    int32_t *__restrict__ uid_of, int32_t *__restrict__ ufirst,
-                                                   int32_t *__restrict__ ulast, int32_t *__restrict__ ulen) {
+                                                   int32_t *__restrict__ ulast, int32_t *__restrict__ ulen, int first_order) {
   const int32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || rep[i] != i) return;
   const int32_t M = pm[n];
-  const int32_t uid = mult[i] > 1 ? pm[i] : M + ps[i];
+  // first_order: one numbering by first occurrence (MinHash's pipelined route: rows [0, R) of the input only use ids < pm[R] + ps[R])
+  const int32_t uid = first_order ? pm[i] + ps[i] : (mult[i] > 1 ? pm[i] : M + ps[i]);
   uid_of[i] = uid;
   ufirst[uid] = i;
   ulast[uid] = last[i];
@@ -1013,10 +1014,11 @@ int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t 
   return DA_OK;
 }
 // Stage 2 (stream-ordered, U = M + S known to the host): unique ids, the unique table's codes / offsets, tile-block bounds.
-int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t U, const NwDedupPlan &p, hipStream_t stream) {
+int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t U, const NwDedupPlan &p, hipStream_t stream,
+                          bool first_order) {
   const unsigned nb = (unsigned)ceil_div(n, 256);
   hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, p.last, p.pm, p.ps, d_off, (int32_t)n, p.uid_of,
-                     p.ufirst, p.ulast, p.ulen);
+                     p.ufirst, p.ulast, p.ulen, first_order ? 1 : 0);
   hipLaunchKernelGGL(k_dd_map, dim3(nb), dim3(256), 0, stream, p.rep, p.uid_of, (int32_t)n, p.uidx);
   hipLaunchKernelGGL(k_dd_scan<int64_t>, dim3(1), dim3(1024), 0, stream, p.ulen, p.uoff, (int32_t)U);
   hipLaunchKernelGGL(k_dd_gather, dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, stream, d_codes, d_off, p.ufirst, p.uoff, (int32_t)U, p.ucodes);

@@ -294,8 +294,14 @@ def mh_last_route():
                                               ctypes.addressof(ms)))
     # route 1 = duplicate-collapsing, 2 = sparse (signatures rarely agree: matching incidences bucketed per tile; then `unique` carries their
     # number, k2_ms the bucket phase and expand_ms the tile pass), 0 = the direct kernels
+    # 4 = route 1 with the ROW expansion (k_expand_stream: no gathered copy; gather_ms = the copy lists, expand_ms = that kernel, border_ms = 0)
+    # 3 = route 1 in its pipelined form (table compared band by band on a side stream while finished row bands are expanded: k2_ms is the
+    # compare's span, gather_ms / expand_ms are sums over the chunk launches, all three overlap)
     sparse = t.value == 2
-    return {"n": n.value, "unique": n.value if sparse else u.value, "dedup": t.value == 1, "sparse": sparse,
+    ch, el = ctypes.c_int(0), ctypes.c_int(0)
+    _capi.check(_capi.load().da_mh_last_route_chunks(ctypes.addressof(ch), ctypes.addressof(el)))
+    return {"chunks": ch.value, "expand_launches": el.value, "n": n.value, "unique": n.value if sparse else u.value, "dedup": t.value in (1, 3, 4, 5), "pipelined": t.value in (3, 5),
+            "expansion": {1: "tiles", 3: "tiles, pipelined", 4: "rows", 5: "rows, pipelined"}.get(t.value, ""), "sparse": sparse,
             "sparse_pairs": u.value if sparse else 0, "plane_bits": b.value, "plan_ms": ms[0], "codes_ms": ms[1],
             "k2_ms": ms[2], "gather_ms": ms[3], "expand_ms": ms[4], "border_ms": ms[5]}
 

@@ -227,10 +227,22 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
  * is written once.  Taken when the input has few duplicates (>= 90 % unique), the incidences number <= n_hash / 5000 per pair on average and
  * <= DYNAALIGN_MH_SPARSE_MAX_PAIRS (default 4e8) in all, no value occurs more than 4096 times in a column, <= 32768 repeated values per column, n >= 2048, n_hash <= 2047; DYNAALIGN_MH_NO_SPARSE=1 disables it.
  * Then *dedup_taken_out = 2, *unique_out = the number of incidences and the times are {plan, K1 + K1b, buckets, 0, tile pass, 0}.
+ * The duplicate route's expansion has two kernel families, each with a form PIPELINED with K2 (DYNAALIGN_MH_EXPAND = rowspipe | rows | pipe |
+ * tiles picks one; default: the first whose shape test passes; DYNAALIGN_MH_NO_PIPE=1 takes the pipelined forms out):
+ *   rows (*dedup_taken_out = 4)   K2 on the table, then ONE pass that holds a table row in LDS and writes the output rows of its copies
+ *                                 (16-byte stores: needs an even ld and a 16-byte aligned d_out); times {plan, K1 + K1b, K2, copy lists, that pass, 0}
+ *   tiles (= 1)                   K2, column gather, tile expansion + diagonal / border tiles (the times listed above)
+ *   rowspipe (= 5), pipe (= 3)    the same kernels with the table compared in bands of 1024 rows by a persistent kernel on a side stream (needs 12
+ *                                 code planes and n_hash > 32) while the finished table rows are expanded; unique strings are numbered by first
+ *                                 occurrence.  The times are then {plan, K1 + K1b, the compare's span, copy lists (rows) / sum of the gather launches
+ *                                 (tiles), time some expansion launch was running, diagonal / border tiles} -- the middle three overlap;
+ *                                 da_mh_last_route_chunks gives the number of chunks and of expansion launches.
+ * All forms write the same bits.
  * Any pointer may be NULL. */
 int da_dev_similarity_mh(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n, int64_t total_residues,
                          int k, int n_hash, const uint32_t *d_seeds, double *d_out, int64_t ld, void *stream);
 int da_mh_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, int *plane_bits_out, double *ms6_out);
+int da_mh_last_route_chunks(int *chunks_out, int *expand_launches_out);
 
 /* ---- the pieces of the duplicate-collapsing routes, for callers that orchestrate the steps themselves (the one-process-per-GPU
  * sharded drivers: every rank builds the same plan, computes ITS shard of the unique table with the *_shard / *_unique_rows calls

@@ -104,9 +104,20 @@ def test_every_signature_row_and_2000_count_rows_against_the_oracle(da, h3n2, bu
     out.fill_(-1.0)
     device.similarity_mh(ds, K, N_HASH, seeds, out=out)
     route = device.mh_last_route()
-    assert route["dedup"] and route["unique"] == len(set(h3n2["seqs"]))
+    assert route["dedup"] and route["expansion"] == "rows, pipelined" and route["unique"] == len(set(h3n2["seqs"]))
     _same_bits(out, ref)
     assert bool((torch.diagonal(out) == 1.0).all())
+    # ... and the route's other forms: the row expansion after K2, the tile expansion pipelined with K2 and one kernel after the other
+    for form, name in (("rows", "rows"), ("pipe", "tiles, pipelined"), ("tiles", "tiles")):
+        out.fill_(-1.0)
+        os.environ["DYNAALIGN_MH_EXPAND"] = form
+        try:
+            device.similarity_mh(ds, K, N_HASH, seeds, out=out)
+        finally:
+            del os.environ["DYNAALIGN_MH_EXPAND"]
+        route = device.mh_last_route()
+        assert route["dedup"] and route["expansion"] == name
+        _same_bits(out, ref)
 
 
 def test_uniform_100k_count_rows_against_the_oracle(da, bufs):

@@ -120,6 +120,102 @@ def test_h3n2_like_12000_properties(da):
     assert torch.equal(out, out.T) and bool((out.diagonal() == 1.0).all())
 
 
+@pytest.mark.parametrize("pool,n,n_hash,env", [(3000, 8000, 100, {"DYNAALIGN_MH_PIPE_STEP": "1"}),
+                                               (3000, 8000, 100, {"DYNAALIGN_MH_PIPE_STEP": "1", "DYNAALIGN_MH_PIPE_ONE_STREAM": "1"}),
+                                               (4200, 9000, 64, {"DYNAALIGN_MH_PIPE_WG": "1"}), (2500, 5000, 33, {"DYNAALIGN_MH_PIPE_WG": "4", "DYNAALIGN_MH_PIPE_STEP": "2"}),
+                                               (2000, 2600, 500, {"DYNAALIGN_MH_PIPE_STEP": "1"})])
+def test_pipelined_form_equals_one_stream_form_and_oracle(da, monkeypatch, pool, n, n_hash, env):
+    """api.cpp "PIPELINED form": the unique table compared band by band on a side stream while finished output row bands are gathered
+    and expanded -- several chunks (U > 1024), every schedule switch; bit-identical to the one-stream form and the oracle
+    (reference src/minHash.cpp:119-188)"""
+    from dynaalign_amd import synth
+    rng = np.random.RandomState(pool + n)
+    base = sorted(set(synth.to_strings(*synth.h3n2_like(pool, 20))))
+    seqs = [base[i] for i in rng.randint(0, len(base), n)]
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    monkeypatch.setenv("DYNAALIGN_PLANE_BITS", "12")          # sets this small get 8 code planes by themselves; the banded compare is the 12-plane kernel
+    monkeypatch.setenv("DYNAALIGN_MH_EXPAND", "pipe")
+    out, route = run(seqs, 4, n_hash)
+    assert route["dedup"] and route["pipelined"] and route["unique"] == len(set(seqs)) and route["unique"] > 1024 and route["chunks"] >= 2
+    monkeypatch.setenv("DYNAALIGN_MH_EXPAND", "tiles")
+    one, route1 = run(seqs, 4, n_hash)
+    assert route1["dedup"] and route1["expansion"] == "tiles"
+    assert same(out, one)
+    monkeypatch.setenv("DYNAALIGN_MH_EXPAND", "rows")
+    rows, route2 = run(seqs, 4, n_hash)
+    assert route2["dedup"] and route2["expansion"] == "rows"
+    assert same(out, rows)
+    monkeypatch.delenv("DYNAALIGN_MH_EXPAND")                 # the default: the row expansion pipelined with K2
+    monkeypatch.setenv("DYNAALIGN_MH_PIPE_HEAD", "1")
+    rp, route3 = run(seqs, 4, n_hash)
+    assert route3["dedup"] and route3["expansion"] == "rows, pipelined" and route3["chunks"] >= 2
+    assert same(out, rp)
+    assert same(out, oracle(seqs, 4, n_hash))
+
+
+def test_pipelined_form_needs_two_stages_of_twelve_planes(da, monkeypatch):
+    """n_hash <= 32 (a single stage: the persistent compare does not take it) stays with the one-stream form"""
+    from dynaalign_amd import synth
+    base = synth.to_strings(*synth.h3n2_like(1500, 20))
+    seqs = base + base[::-1]
+    monkeypatch.setenv("DYNAALIGN_PLANE_BITS", "12")
+    monkeypatch.setenv("DYNAALIGN_MH_EXPAND", "pipe")
+    out, route = run(seqs, 4, 32)
+    assert route["dedup"] and route["expansion"] == "tiles"
+    assert same(out, oracle(seqs, 4, 32))
+
+
+@pytest.mark.parametrize("form", ["rows", "rowspipe", "tiles", "pipe"])
+def test_expansion_forms_on_awkward_sets(da, small_n_route, monkeypatch, form):
+    """the expansions of the unique table (api.cpp: rows = k_expand_stream, tiles = gather + k_expand_rows, rowspipe / pipe = these pipelined with K2):
+    odd n, one string with hundreds of copies (more than ES_COPIES = 4 per work item) next to single-copy strings, empty and shorter-than-k
+    strings, n_hash not a multiple of 32 -- each form against the oracle (reference src/minHash.cpp:119-188)"""
+    rng = np.random.RandomState(17)
+    singles = duplicated_set(rng, 1, 0, 140, 15, 30)
+    seqs = singles[:70] + [singles[3]] * 333 + ["", "AC", "ACD"] * 7 + singles[70:] + [singles[100]] * 5 + [singles[101]] * 4 + [singles[102]] * 6
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    assert len(seqs) % 2 == 1
+    import torch
+    from dynaalign_amd import device
+    import dynaalign_amd as da_
+    monkeypatch.setenv("DYNAALIGN_MH_EXPAND", form)
+    monkeypatch.setenv("DYNAALIGN_PLANE_BITS", "12")          # (the pipelined forms need the 12-plane compare; a set this small gets 8 planes by itself)
+    n = len(seqs)
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(np.asarray(res, np.uint8), np.asarray(off, np.int64))
+    for n_hash in (70, 500):
+        buf = torch.full((n, n + 1), -1.0, dtype=torch.float64, device="cuda")     # odd n: an even leading dimension for the 16-byte stores
+        device.similarity_mh(ds, 4, n_hash, da_.hash_family_seeds(12345, n_hash), out=buf[:, :n])
+        route = device.mh_last_route()
+        assert route["dedup"] and route["unique"] == len(set(seqs))
+        assert route["expansion"] == {"rows": "rows", "rowspipe": "rows, pipelined", "tiles": "tiles", "pipe": "tiles, pipelined"}[form]
+        assert same(buf[:, :n].cpu().numpy(), oracle(seqs, 4, n_hash)) and bool((buf[:, n] == -1.0).all())
+
+
+def test_row_expansion_needs_an_even_leading_dimension(da, small_n_route):
+    """16-byte stores: an odd ld or an unaligned result takes the tile forms (which have their own element-wise fallback)"""
+    import torch
+    from dynaalign_amd import device
+    import dynaalign_amd as da_
+    rng = np.random.RandomState(5)
+    seqs = duplicated_set(rng, 50, 400, 80, 12, 25)
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(np.asarray(res, np.uint8), np.asarray(off, np.int64))
+    n = len(seqs)
+    seeds = da_.hash_family_seeds(12345, 64)
+    buf = torch.full((n, n + 1), -1.0, dtype=torch.float64, device="cuda")
+    device.similarity_mh(ds, 4, 64, seeds, out=buf[:, :n])
+    route = device.mh_last_route()
+    assert route["dedup"] and route["expansion"] != "rows"
+    assert same(buf[:, :n].cpu().numpy(), oracle(seqs, 4, 64)) and bool((buf[:, n] == -1.0).all())
+    buf2 = torch.full((n, n + 2), -1.0, dtype=torch.float64, device="cuda")
+    device.similarity_mh(ds, 4, 64, seeds, out=buf2[:, :n])
+    assert device.mh_last_route()["expansion"] == "rows"
+    assert same(buf2[:, :n].cpu().numpy(), oracle(seqs, 4, 64)) and bool((buf2[:, n:] == -1.0).all())
+
+
 def test_degenerate_unique_tables(da, small_n_route):
     """U = 1 (every sequence identical), U = 2, and a set whose duplicates all sit at the end / the start"""
     a, b = "ACDEFGHIKLMNPQRSTVWY", "YWVTSRQPNMLKIHGFEDCA"

@@ -10,6 +10,9 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu $*"
+# counters are per dispatch and the profiler serialises kernels: profile the one-stream form of the duplicate route (one launch of
+# k_expand_rows / k_gather_columns / the compare per step; the pipelined form splits the same work over its chunk launches)
+export DYNAALIGN_MH_NO_PIPE=1
 export BENCH_ARGS="$ARGS"
 run() { # name, counters...
   local name=$1; shift
