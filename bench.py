@@ -148,7 +148,11 @@ def pmc_kernel(kernel, n):
                 d = json.load(open(os.path.join(pdir, f)))
             except Exception:
                 continue
-            k = d.get("kernels", {}).get(kernel)
+            ks = d.get("kernels", {})
+            k = ks.get(kernel)
+            if k is None:                        # template instances are profiled under their full name ("k_expand_stream<true, 6>")
+                inst = sorted(nm for nm in ks if nm.startswith(kernel + "<"))
+                k = ks[inst[0]] if len(inst) == 1 else None
             if k and d.get("n") == n:
                 best = dict(k, source="profiles/" + f, source_hash=d.get("source_hash"))
     return best

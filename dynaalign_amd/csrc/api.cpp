@@ -717,7 +717,10 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       // the row expansion PIPELINED with K2: the first `head` bands of the table at full occupancy, the rest by the persistent kernel with `wg`
       // workgroup(s) per CU on a side stream (one 36 KB ring fits beside the expansion's 94 KB row) while the finished table rows are expanded
       const int64_t KB = mh_sym_bands(U);
-      int step = 4, wg = 1, head = 4;                              // (head 2-6 x step 3-6 measure within 0.3 ms of each other, profiles/r03_m_*)
+      // K2 rings (36 KB, 128 VGPRs x 4 waves) that fit beside one expansion workgroup: two when its LDS row is packed (n_hash <= 511), else one --
+      // and a slower K2 wants a head start and smaller chunks (profiles/r03_m_pipeline_rows_*.txt: head x step sweeps for both)
+      const bool two = expand_stream_packed(n_hash);
+      int wg = two ? 2 : 1, head = two ? 1 : 4, step = two ? 8 : 4;
       if (const char *e = getenv("DYNAALIGN_MH_PIPE_STEP")) step = std::max(1, atoi(e));
       if (const char *e = getenv("DYNAALIGN_MH_PIPE_WG")) wg = std::max(1, std::min(4, atoi(e)));
       if (const char *e = getenv("DYNAALIGN_MH_PIPE_HEAD")) head = std::max(1, atoi(e));
@@ -740,7 +743,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
         const hipStream_t es = alt ? pr->alt[c & 1] : stream;
         DA_HIP_TRY(hipStreamWaitEvent(es, pe[3 * c], 0));
         DA_HIP_TRY(hipEventRecord(pe[3 * c + 1], es));
-        if ((rc = launch_expand_stream_rows(dtab.as<uint16_t>(), ld_d, p.uidx, n, U, n_hash, d_out, ld, lists.p, cuts[c] * 1024, cuts[c + 1] * 1024, es)) != DA_OK) return rc;
+        if ((rc = launch_expand_stream_rows(dtab.as<uint16_t>(), ld_d, p.uidx, n, U, n_hash, d_out, ld, lists.p, cuts[c] * 1024, cuts[c + 1] * 1024, es, (int)c)) != DA_OK) return rc;
         DA_HIP_TRY(hipEventRecord(pe[3 * c + 2], es));
       }
       if (alt) for (size_t c = (C >= 2 ? C - 2 : 0); c < C; ++c) DA_HIP_TRY(hipStreamWaitEvent(stream, pe[3 * c + 2], 0));

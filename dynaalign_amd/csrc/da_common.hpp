@@ -181,11 +181,12 @@ int launch_expand_unique(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
 // ROW expansion (MinHash: symmetric table): every output row written once from its table row held in LDS; no gathered copy
 bool expand_stream_ok(int64_t n, int64_t U, int n_hash, const void *d_out, int64_t ld);
 size_t expand_stream_scratch_bytes(int64_t n, int64_t U);
+bool expand_stream_packed(int n_hash);   // the LDS row is packed to 9 bits per count: two K2 rings fit beside it
 int launch_expand_stream(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int64_t U, int n_hash, double *d_out, int64_t ld,
                          void *d_scratch, hipStream_t stream, hipEvent_t after_lists = nullptr);
 int launch_expand_stream_lists(const int32_t *d_uidx, int64_t n, int64_t U, void *d_scratch, hipStream_t stream);
 int launch_expand_stream_rows(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int64_t U, int n_hash, double *d_out, int64_t ld,
-                              void *d_scratch, int64_t row_begin, int64_t row_end, hipStream_t stream);
+                              void *d_scratch, int64_t row_begin, int64_t row_end, hipStream_t stream, int launch_no);   // launch_no: 0 .. 127, distinct per launch of a call
 int launch_expand_rows(const uint16_t *d_F, int64_t ld_f, const int32_t *d_uidx, int64_t n, bool is_nw, int n_hash, int nw_max_len,
                        double *d_out, int64_t ld, int64_t band_begin, int64_t band_end, hipStream_t stream);
 // bytes of the column-gathered table (d_F) that switches launch_expand_unique to its two streaming passes; 0 = shape not covered

@@ -2415,7 +2415,7 @@ __global__ __launch_bounds__(256, 4) void k_expand_rows(const uint16_t *__restri
 // written exactly once (diagonal and borders included: no second kernel), a wave-instruction covers 1 KiB of one output row, and the
 // only global reads are the table rows (4 GB) and the id map (L2-resident).  Work items are (unique row, up to ES_COPIES of its copies),
 // listed by k_es_items so that a string with thousands of copies is spread over many workgroups.
-constexpr int ES_THREADS = 1024, ES_COPIES = 4;
+constexpr int ES_THREADS = 1024, ES_COPIES = 4, ES_TICKETS = 128;   // (ticket counters: one per launch of a call, launch_expand_stream_rows' `launch_no`)
 __global__ __launch_bounds__(256) void k_es_count(const int32_t *__restrict__ uidx, int n, uint32_t *__restrict__ cnt) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) atomicAdd(&cnt[uidx[i]], 1u);
@@ -2468,39 +2468,73 @@ __global__ __launch_bounds__(256) void k_es_fill(const int32_t *__restrict__ uid
     for (uint32_t q = 0; q < cnt; ++q) items[first + q] = make_int2(i, (int)(q * ES_COPIES));
   }
 }
-__global__ __launch_bounds__(ES_THREADS) void k_expand_stream(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
+// count / n_hash without a table and without the division sequence: with r = RN(1 / b), q0 = RN(a r), e = a - q0 b (exact in one FMA),
+// RN(q0 + e r) IS the correctly rounded quotient a / b (Markstein's final step; checked exhaustively for every 0 <= a <= b <= 65535 on the
+// host, and on the device by da_debug_ratio_check / tests/test_gpu_mh_dedup.py) -- what src/minHash.cpp:174 computes with a divide.
+// The table lookups were the row expansion's heaviest LDS traffic, and LDS bandwidth is what the co-running compare kernel needs.
+__device__ __forceinline__ double es_ratio(uint32_t c, double dn, double rcp) {
+  const double dc = (double)c, q0 = __dmul_rn(dc, rcp), e = __fma_rn(-q0, dn, dc);
+  return __fma_rn(e, rcp, q0);
+}
+__global__ __launch_bounds__(256) void k_es_ratio_check(int n_hash, double *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const double dn = (double)n_hash, rcp = 1.0 / dn;
+  if (c <= n_hash) out[c] = es_ratio((uint32_t)c, dn, rcp);
+}
+// PACKED (counts <= 511, i.e. n_hash <= 511): the LDS row holds the low byte of every count + one bit plane for bit 8 -- 9/16 of the bytes (54.6 KB
+// instead of 93.9 KB at U = 44 931), which lets TWO rings of the persistent compare kernel stay resident beside it in the pipelined form
+template <bool PACKED, int NQ>                // NQ: 16-byte units of a table row per thread, ceil(U / 8192) rounded up to 2, 4, 6 or 8
+__global__ __launch_bounds__(ES_THREADS, 8)   // <= 64 VGPRs: the 4 waves per SIMD of one workgroup leave 256 VGPRs = two K2 waves
+void k_expand_stream(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t *__restrict__ uidx,
                                                               const uint32_t *__restrict__ cstart, const int32_t *__restrict__ cpos,
                                                               const int2 *__restrict__ items, const uint32_t *__restrict__ istart, int row_begin,
-                                                              int row_end, int n, int n_hash, double *__restrict__ out, int64_t ld) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char es_lds[];   // count -> double table (n_hash + 1 entries, padded to 16 B), then the table row
-  double *tab = reinterpret_cast<double *>(es_lds);
-  const int tab_bytes = ((n_hash + 1) * 8 + 15) & ~15;
-  uint16_t *row = reinterpret_cast<uint16_t *>(es_lds + tab_bytes);
+                                                              int row_end, int n, int n_hash, double *__restrict__ out, int64_t ld,
+                                                              uint32_t *__restrict__ ticket) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char es_lds[];   // the table row
+  uint16_t *row = reinterpret_cast<uint16_t *>(es_lds);
+  unsigned char *row_lo = es_lds, *row_hi = row_lo + ld_d;           // (PACKED) ld_d low bytes, then ld_d / 8 bytes of bit 8
   const int tid = threadIdx.x;
-  for (int e = tid; e <= n_hash; e += ES_THREADS) tab[e] = (double)e / (double)n_hash;              // src/minHash.cpp:174
+  const double dn = (double)n_hash, rcp = 1.0 / dn;                  // src/minHash.cpp:174 (es_ratio)
+  auto count_of = [&](int c) -> uint32_t {
+    if (!PACKED) return row[c];
+    return (uint32_t)row_lo[c] | ((((uint32_t)row_hi[c >> 3] >> (c & 7)) & 1u) << 8);
+  };
   const int n_items = (int)istart[row_end];                          // the items of the table rows [row_begin, row_end)
   const int units = (int)(ld_d >> 3);
-  uint4 pre[8];
+  uint4 pre[NQ];
 #define ES_FETCH(r_)                                                                                    \
   {                                                                                                     \
     const uint4 *src_ = reinterpret_cast<const uint4 *>(D + (int64_t)(r_) * ld_d);                      \
-    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                     \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
       const int u = tid + q * ES_THREADS;                                                               \
       pre[q] = u < units ? src_[u] : make_uint4(0, 0, 0, 0);                                            \
     }                                                                                                   \
   }
-  int k = (int)istart[row_begin] + (int)blockIdx.x;
+  // a workgroup's first item is its block index, the following ones come from a ticket counter: items carry 1 ... ES_COPIES output rows, a
+  // static deal leaves the slowest workgroup ~8 % behind the mean
+  __shared__ int s_next;
+  const int base = (int)istart[row_begin];
+  int k = base + (int)blockIdx.x;
   int2 it = k < n_items ? items[k] : make_int2(0, 0);
   if (k < n_items) ES_FETCH(it.x)
   const int2 *u2 = reinterpret_cast<const int2 *>(uidx);
   const int j2_end = n >> 1;
-  for (; k < n_items; k += gridDim.x) {
-    __syncthreads();                                                 // the previous item's reads have left the LDS row (and the table is built)
+  while (k < n_items) {
+    __syncthreads();                                                 // the previous item's reads have left the LDS row
+    if (tid == 0) s_next = base + (int)gridDim.x + (int)atomicAdd(ticket, 1u);
     uint4 *dst = reinterpret_cast<uint4 *>(row);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int u = tid + q * ES_THREADS;
-      if (u < units) dst[u] = pre[q];
+      if (u >= units) continue;
+      if (!PACKED) { dst[u] = pre[q]; continue; }
+      const uint4 v = pre[q];                                        // counts 8 u ... 8 u + 7, two per word
+      uint2 lo;
+      lo.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);           // bytes 0 and 2 of x, then of y
+      lo.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u);
+      *reinterpret_cast<uint2 *>(row_lo + 8 * u) = lo;
+      row_hi[u] = (unsigned char)(((v.x >> 8) & 1u) | ((v.x >> 23) & 2u) | ((v.y >> 6) & 4u) | ((v.y >> 21) & 8u) | ((v.z >> 4) & 16u) |
+                                  ((v.z >> 19) & 32u) | ((v.w >> 2) & 64u) | ((v.w >> 17) & 128u));
     }
     __syncthreads();
     // this item's output rows (wave-uniform), then the next item's table row on its way while this one is expanded
@@ -2509,23 +2543,24 @@ __global__ __launch_bounds__(ES_THREADS) void k_expand_stream(const uint16_t *__
     double *orow[ES_COPIES];
 #pragma unroll
     for (int q = 0; q < ES_COPIES; ++q) orow[q] = out + (int64_t)cpos[c0 + (uint32_t)min(q, ncop - 1)] * ld;
-    const int kn = k + (int)gridDim.x;
+    const int kn = __builtin_amdgcn_readfirstlane(s_next);          // wave-uniform: the item, its output rows and the next table row's address stay scalar
     int2 itn = make_int2(0, 0);
     if (kn < n_items) { itn = items[kn]; ES_FETCH(itn.x) }
 #pragma unroll 4
     for (int j2 = tid; j2 < j2_end; j2 += ES_THREADS) {
       const int2 c = u2[j2];
-      const double v0 = tab[row[c.x]], v1 = tab[row[c.y]];
+      const double v0 = es_ratio(count_of(c.x), dn, rcp), v1 = es_ratio(count_of(c.y), dn, rcp);
       nt_store2(orow[0] + 2 * j2, v0, v1);
       if (ncop > 1) nt_store2(orow[1] + 2 * j2, v0, v1);
       if (ncop > 2) nt_store2(orow[2] + 2 * j2, v0, v1);
       if (ncop > 3) nt_store2(orow[3] + 2 * j2, v0, v1);
     }
     if ((n & 1) && tid == 0) {                                       // odd n: the last column
-      const double v = tab[row[uidx[n - 1]]];
+      const double v = es_ratio(count_of(uidx[n - 1]), dn, rcp);
       for (int q = 0; q < ncop; ++q) orow[q][n - 1] = v;
     }
     it = itn;
+    k = kn;
   }
 #undef ES_FETCH
 }
@@ -2534,15 +2569,22 @@ bool expand_stream_ok(int64_t n, int64_t U, int n_hash, const void *d_out, int64
   return n >= 2 && n <= 0x7fffffffLL && U >= 1 && U <= 65536 && n_hash >= 1 && n_hash <= 2047 && (ld & 1) == 0 &&
          (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && !getenv("DYNAALIGN_EXPAND_NO_STREAM");
 }
+extern "C" int da_debug_ratio_check(int n_hash, double *d_out, void *stream) {   // tests: es_ratio(c) for c = 0 .. n_hash into d_out
+  if (n_hash < 1 || !d_out) return fail(DA_ERR_BAD_ARG, "ratio check: bad arguments");
+  hipLaunchKernelGGL(k_es_ratio_check, dim3((unsigned)(n_hash / 256 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), n_hash, d_out);
+  DA_HIP_TRY(hipGetLastError());
+  return DA_OK;
+}
+bool expand_stream_packed(int n_hash) { return n_hash <= 511 && !getenv("DYNAALIGN_EXPAND_STREAM_U16"); }   // counts fit 9 bits: byte + bit plane in LDS
 size_t expand_stream_scratch_bytes(int64_t n, int64_t U) {
   // cnt[U] + cursor[U] (zeroed together), cstart[U + 1], istart[U + 1], cpos[n], items[U + n / ES_COPIES + 1]
-  return ((size_t)(4 * U + 8) * 4 + (size_t)n * 4 + (size_t)(U + n / ES_COPIES + 2) * 8 + 1024);
+  return ((size_t)(4 * U + 8 + ES_TICKETS) * 4 + (size_t)n * 4 + (size_t)(U + n / ES_COPIES + 2) * 8 + 1024);
 }
-struct EsLists { uint32_t *cnt, *cursor, *cstart, *istart; int32_t *cpos; int2 *items; };
+struct EsLists { uint32_t *cnt, *cursor, *ticket, *cstart, *istart; int32_t *cpos; int2 *items; };
 static EsLists es_layout(void *d_scratch, int64_t n, int64_t U) {
   uint32_t *w = static_cast<uint32_t *>(d_scratch);
   EsLists L;
-  L.cnt = w; L.cursor = w + U; L.cstart = w + 2 * U; L.istart = L.cstart + (U + 1);
+  L.cnt = w; L.cursor = w + U; L.ticket = w + 2 * U; L.cstart = L.ticket + ES_TICKETS; L.istart = L.cstart + (U + 1);   // cnt, cursor, ticket: zeroed together
   L.cpos = reinterpret_cast<int32_t *>(L.istart + (U + 1));
   L.items = reinterpret_cast<int2 *>((reinterpret_cast<uintptr_t>(L.cpos + n) + 15) & ~(uintptr_t)15);
   return L;
@@ -2550,7 +2592,7 @@ static EsLists es_layout(void *d_scratch, int64_t n, int64_t U) {
 // the copy lists of the row expansion (positions of every unique id's copies, work items), stream-ordered
 int launch_expand_stream_lists(const int32_t *d_uidx, int64_t n, int64_t U, void *d_scratch, hipStream_t stream) {
   const EsLists L = es_layout(d_scratch, n, U);
-  DA_HIP_TRY(hipMemsetAsync(L.cnt, 0, (size_t)U * 8, stream));
+  DA_HIP_TRY(hipMemsetAsync(L.cnt, 0, ((size_t)U * 2 + ES_TICKETS) * 4, stream));
   const unsigned nb = (unsigned)ceil_div(std::max(n, U), 256);
   hipLaunchKernelGGL(k_es_count, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, d_uidx, (int)n, L.cnt);
   hipLaunchKernelGGL(k_es_scan, dim3(1), dim3(1024), 0, stream, L.cnt, (int)U, L.cstart, L.istart);
@@ -2560,8 +2602,9 @@ int launch_expand_stream_lists(const int32_t *d_uidx, int64_t n, int64_t U, void
 }
 // k_expand_stream on the table rows [row_begin, row_end) (lists from launch_expand_stream_lists on the same scratch)
 int launch_expand_stream_rows(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uidx, int64_t n, int64_t U, int n_hash, double *d_out, int64_t ld,
-                              void *d_scratch, int64_t row_begin, int64_t row_end, hipStream_t stream) {
-  if (!expand_stream_ok(n, U, n_hash, d_out, ld) || (ld_d & 7) || ld_d > 65536 || (reinterpret_cast<uintptr_t>(d_D) & 15))
+                              void *d_scratch, int64_t row_begin, int64_t row_end, hipStream_t stream, int launch_no) {
+  if (!expand_stream_ok(n, U, n_hash, d_out, ld) || (ld_d & 7) || ld_d > 65536 || (reinterpret_cast<uintptr_t>(d_D) & 15) || launch_no < 0 ||
+      launch_no >= ES_TICKETS)
     return fail(DA_ERR_UNSUPPORTED, "row expansion: shape not covered");
   if (row_end > U) row_end = U;
   if (row_begin >= row_end) return DA_OK;
@@ -2573,17 +2616,28 @@ int launch_expand_stream_rows(const uint16_t *d_D, int64_t ld_d, const int32_t *
   if (!((es_attr_done.load() >> (dev & 63)) & 1u)) {
     hipDeviceProp_t prop;
     DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2 + 2048 * 8));
+#define DA_ES_ATTR(P, Q) DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_stream<P, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2))
+    DA_ES_ATTR(false, 2); DA_ES_ATTR(false, 4); DA_ES_ATTR(false, 6); DA_ES_ATTR(false, 8);
+    DA_ES_ATTR(true, 2); DA_ES_ATTR(true, 4); DA_ES_ATTR(true, 6); DA_ES_ATTR(true, 8);
+#undef DA_ES_ATTR
     es_cus.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     es_attr_done.fetch_or(1ull << (dev & 63));
   }
-  const size_t lds = (size_t)(((n_hash + 1) * 8 + 15) & ~15) + (size_t)ld_d * 2;
-  const int wg_per_cu = lds <= 76 * 1024 ? 2 : 1;                      // resident workgroups per CU the LDS row allows (of 2 x 16 waves)
-  int64_t grid = (int64_t)es_cus.load() * wg_per_cu;
+  const bool packed = expand_stream_packed(n_hash);
+  size_t lds = packed ? (size_t)ld_d + (size_t)ld_d / 8 : (size_t)ld_d * 2;
+  // never two of these workgroups on one CU (the pipelined form's consecutive launches would otherwise fill the VGPR file with 8 waves per SIMD
+  // and lock the compare kernel out until the older launch has drained): ask for more than half of the CU's 160 KB
+  lds = std::max<size_t>(lds, 82 * 1024);
+  // one resident workgroup (16 waves) per CU: every workgroup of the grid must be resident from the start (first items are dealt by block index)
+  int64_t grid = (int64_t)es_cus.load();
   if (const char *e = getenv("DYNAALIGN_EXPAND_STREAM_GRID")) grid = std::max(1, atoi(e));
   grid = std::min<int64_t>(grid, (row_end - row_begin) + n / ES_COPIES + 1);
-  hipLaunchKernelGGL(k_expand_stream, dim3((unsigned)grid), dim3(ES_THREADS), lds, stream, d_D, ld_d, d_uidx, L.cstart, L.cpos, L.items, L.istart,
-                     (int)row_begin, (int)row_end, (int)n, n_hash, d_out, ld);
+#define DA_ES(P, Q) hipLaunchKernelGGL((k_expand_stream<P, Q>), dim3((unsigned)grid), dim3(ES_THREADS), lds, stream, d_D, ld_d, d_uidx, L.cstart, L.cpos, L.items, \
+                                       L.istart, (int)row_begin, (int)row_end, (int)n, n_hash, d_out, ld, L.ticket + launch_no)
+  const int64_t nq = ceil_div(ld_d >> 3, ES_THREADS);                 // 16-byte units of a row per thread
+  if (packed) { if (nq <= 2) DA_ES(true, 2); else if (nq <= 4) DA_ES(true, 4); else if (nq <= 6) DA_ES(true, 6); else DA_ES(true, 8); }
+  else { if (nq <= 2) DA_ES(false, 2); else if (nq <= 4) DA_ES(false, 4); else if (nq <= 6) DA_ES(false, 6); else DA_ES(false, 8); }
+#undef DA_ES
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
@@ -2593,7 +2647,7 @@ int launch_expand_stream(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
   int rc = launch_expand_stream_lists(d_uidx, n, U, d_scratch, stream);
   if (rc != DA_OK) return rc;
   if (after_lists) DA_HIP_TRY(hipEventRecord(after_lists, stream));
-  return launch_expand_stream_rows(d_D, ld_d, d_uidx, n, U, n_hash, d_out, ld, d_scratch, 0, U, stream);
+  return launch_expand_stream_rows(d_D, ld_d, d_uidx, n, U, n_hash, d_out, ld, d_scratch, 0, U, stream, 0);
 }
 
 // device bytes of the column-gathered table the two-pass expansion wants (0: the shape is not covered, pass NULL)

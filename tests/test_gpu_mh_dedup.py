@@ -185,13 +185,33 @@ def test_expansion_forms_on_awkward_sets(da, small_n_route, monkeypatch, form):
     n = len(seqs)
     res, off = O.pack(seqs)
     ds = device.DeviceSequences(np.asarray(res, np.uint8), np.asarray(off, np.int64))
-    for n_hash in (70, 500):
+    for n_hash in (70, 500, 640):                              # (640: counts need 10 bits -- the row expansion's unpacked LDS row)
         buf = torch.full((n, n + 1), -1.0, dtype=torch.float64, device="cuda")     # odd n: an even leading dimension for the 16-byte stores
         device.similarity_mh(ds, 4, n_hash, da_.hash_family_seeds(12345, n_hash), out=buf[:, :n])
         route = device.mh_last_route()
         assert route["dedup"] and route["unique"] == len(set(seqs))
         assert route["expansion"] == {"rows": "rows", "rowspipe": "rows, pipelined", "tiles": "tiles", "pipe": "tiles, pipelined"}[form]
         assert same(buf[:, :n].cpu().numpy(), oracle(seqs, 4, n_hash)) and bool((buf[:, n] == -1.0).all())
+
+
+def test_row_expansion_quotient_equals_the_divide_for_every_count(da):
+    """k_expand_stream forms count / n_hash as RN(q0 + (c - q0 n) r), r = RN(1 / n), q0 = RN(c r) (minhash_kernels.hip es_ratio) instead of
+    dividing (src/minHash.cpp:174): the same double for EVERY 0 <= c <= n_hash, n_hash = 1 .. 2047 and a few larger -- run on the device"""
+    import ctypes
+    import torch
+    from dynaalign_amd import _capi
+    lib = _capi.load()
+    lib.da_debug_ratio_check.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.da_debug_ratio_check.restype = ctypes.c_int
+    sizes = list(range(1, 2048)) + [4096, 9999, 65535]
+    buf = torch.zeros(sum(s_ + 1 for s_ in sizes), dtype=torch.float64, device="cuda")
+    pos = 0
+    for n_hash in sizes:
+        assert lib.da_debug_ratio_check(n_hash, buf.data_ptr() + 8 * pos, None) == 0
+        pos += n_hash + 1
+    got = buf.cpu().numpy()
+    want = np.concatenate([np.arange(s_ + 1, dtype=np.float64) / float(s_) for s_ in sizes])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
 
 
 def test_row_expansion_needs_an_even_leading_dimension(da, small_n_route):
