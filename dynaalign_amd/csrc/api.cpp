@@ -950,6 +950,20 @@ int da_dev_expand_unique(const uint16_t *d_table, int64_t ld_table, int table_wo
   if (!is_nw && (n_hash <= 0 || n_hash > 65535)) return fail(DA_ERR_BAD_NHASH, "%s", da_status_message(DA_ERR_BAD_NHASH));
   if (table_world < 1) return fail(DA_ERR_BAD_ARG, "table_world must be >= 1");
   const int64_t rows_local = table_world > 1 ? ceil_div(ceil_div(U, 128), table_world) * 128 : 0;
+  // MinHash (symmetric table, one block): the ROW expansion -- every output row written once from its table row in LDS, no gathered copy
+  // (minhash_kernels.hip k_expand_stream; DYNAALIGN_EXPAND_NO_STREAM=1 keeps the tile passes).  The copy lists live in the caller's workspace.
+  if (!is_nw && table_world == 1 && expand_stream_ok(n, U, n_hash, d_out, ld) && (ld_table & 7) == 0 && ld_table <= 65536 &&
+      (reinterpret_cast<uintptr_t>(d_table) & 15) == 0) {
+    const size_t lists_bytes = expand_stream_scratch_bytes(n, U);
+    if (d_work && work_bytes >= lists_bytes && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0)
+      return launch_expand_stream(d_table, ld_table, plan->d_uidx, n, U, n_hash, d_out, ld, d_work, static_cast<hipStream_t>(stream));
+    DevBuf lists;
+    int rc = lists.alloc(lists_bytes);
+    if (rc != DA_OK) return rc;
+    rc = launch_expand_stream(d_table, ld_table, plan->d_uidx, n, U, n_hash, d_out, ld, lists.p, static_cast<hipStream_t>(stream));
+    DA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // the lists go away with this frame
+    return rc;
+  }
   const size_t need = expand_rows_workspace_bytes(n, U, DA_OUT_F64, is_nw != 0, n_hash, nw_max_len);
   uint16_t *d_F = (need && d_work && work_bytes >= need && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0) ? static_cast<uint16_t *>(d_work) : nullptr;
   if ((ld_table & 7) || (reinterpret_cast<uintptr_t>(d_table) & 15)) d_F = nullptr;     // the column gather reads the table in 16-byte units

@@ -293,7 +293,10 @@ int da_dev_extract_edges_rows(const uint16_t *d_rows, int64_t ld, const int32_t 
  * (is_nw = 0) or matches / length (is_nw = 1, nw_max_len = longest sequence).  table_world = 1: row r of the table is row r; > 1: the
  * table is the all-gathered row blocks of cyclic 128-row units (rank p computed units p, p + world, ...; every block holds
  * ceil(ceil(unique / 128) / world) * 128 rows).  d_work: da_dev_expand_workspace_bytes bytes (the column-gathered twin of the
- * table for the two streaming passes; with less, or NULL, the one-kernel expansion runs). */
+ * table for the two streaming passes; with less, or NULL, the one-kernel expansion runs).  MinHash tables in one block (is_nw = 0, table_world = 1;
+ * the table must be the full symmetric square) with an even ld, a 16-byte aligned d_out, unique <= 65536 and n_hash <= 2047 take the ROW expansion
+ * instead (every output row written once from its table row held in LDS; d_work then only holds a few MB of copy lists; DYNAALIGN_EXPAND_NO_STREAM=1
+ * keeps the tile passes). */
 size_t da_dev_expand_workspace_bytes(int64_t n, int64_t unique, int is_nw, int n_hash, int nw_max_len);
 int da_dev_expand_unique(const uint16_t *d_table, int64_t ld_table, int table_world, const da_unique_plan *plan, int is_nw, int n_hash,
                          int nw_max_len, void *d_work, size_t work_bytes, double *d_out, int64_t ld, void *stream);
