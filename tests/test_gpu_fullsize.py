@@ -120,6 +120,50 @@ def test_every_signature_row_and_2000_count_rows_against_the_oracle(da, h3n2, bu
         _same_bits(out, ref)
 
 
+def test_row_expansion_with_more_than_49152_unique_strings(da, h3n2, bufs):
+    """the duplicate route on a set with 51 000+ unique strings of 100 000 (k_expand_stream's deepest prefetch, <true, 8>; K2's table has 50 bands),
+    and with n_hash = 640 (counts need 10 bits: the unpacked LDS row, one K2 workgroup per CU in the pipeline): rows / rows pipelined / tiles over
+    the whole matrix, and whole rows of the result against the oracle's compare loop"""
+    from dynaalign_amd import device, synth
+    rng = np.random.RandomState(99)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    seqs = list(h3n2["seqs"][:88000]) + ["".join(map(chr, alpha[rng.randint(0, 20, 20)])) for _ in range(12000)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    unique = len(set(seqs))
+    assert 49152 < unique <= 60000
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(np.asarray(res, np.uint8), np.asarray(off, np.int64))
+    ref, out = bufs
+    for n_hash in (500, 640):
+        seeds = da.hash_family_seeds(SEED, n_hash)
+        got = {}
+        for form, name in (("tiles", "tiles"), ("rows", "rows"), ("rowspipe", "rows, pipelined")):
+            os.environ["DYNAALIGN_MH_EXPAND"] = form
+            try:
+                dst = ref if form == "tiles" else out
+                dst.fill_(-1.0)
+                device.similarity_mh(ds, K, n_hash, seeds, out=dst)
+            finally:
+                del os.environ["DYNAALIGN_MH_EXPAND"]
+            route = device.mh_last_route()
+            if form == "rowspipe" and route["plane_bits"] != 12:          # (the added random peptides can push the dictionary past 12 code planes:
+                name = "rows"                                              #  the banded compare is the 12-plane kernel, so no pipeline then)
+            assert route["dedup"] and route["expansion"] == name and route["unique"] == unique
+            if form != "tiles":
+                _same_bits(out, ref)
+        sig = O.signatures(seqs, K, n_hash, seeds) if n_hash == 640 else None
+        if sig is not None:                                                     # whole rows against the oracle (its signatures, its compare loop)
+            ratio = np.arange(n_hash + 1, dtype=np.float64) / n_hash
+
+            def rows_of(a, b):
+                blk = ref[a:b].cpu().numpy()
+                cnt = np.searchsorted(ratio, blk)
+                assert np.array_equal(ratio[cnt], blk)
+                return cnt.astype(np.uint16)
+            assert _check_count_rows(rows_of, sig, nblocks=6, rows=48) >= 200
+
+
 def test_uniform_100k_count_rows_against_the_oracle(da, bufs):
     """no duplicates to collapse, 15-bit dictionary codes -> the hand-scheduled 16-plane kernel"""
     from dynaalign_amd import device, synth
