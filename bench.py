@@ -539,6 +539,15 @@ def main():
         line["route"] = {"n": n, "unique": state["unique"], "dedup": state["dedup"],
                          "note": "dedup: every rank builds the same duplicate plan, the ranks shard the count table of the unique strings "
                                  "(one all-gather of (U/n)^2 of the bytes) and expand it locally; direct: the n x n pair space is sharded"}
+        # beside the sharded step: every rank computing the whole matrix by itself (the single-GPU call, no collective).  The dense result is
+        # replicated on every rank either way, so when the compare is cheap next to the N x N stores (duplicates collapsed: 5 of 17 ms) sharding
+        # it cannot pay for its all-gather -- this leg says by how much.  Not `value`: the north-star's N > 1 configuration is the sharded one.
+        rsteps = max(2, min(a.steps, 3))
+        rdt, revs = timed_steps(lambda: (device.similarity_mh(ds, k, n_hash, d_seeds, out=out), device.mh_last_route())[1], rsteps, 1)
+        line["replicas_no_collective"] = {"ms_per_step": rdt / rsteps * 1e3, "value": pairs_mh / (rdt / rsteps), "unit": "pairs/s", "steps": rsteps,
+                                          "route": {k_: revs[-1][k_] for k_ in ("dedup", "pipelined", "expansion", "unique", "plane_bits")},
+                                          "note": "each rank runs da_dev_similarity_mh on the whole set (same result on every rank, no exchange); "
+                                                  "barrier-bracketed, max over ranks"}
 
     # ---- similarityNW on the same set (second half of the metric), >= 3 timed launches
     if not a.no_nw:
