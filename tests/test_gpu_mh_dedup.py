@@ -154,6 +154,58 @@ def test_pipelined_form_equals_one_stream_form_and_oracle(da, monkeypatch, pool,
     assert same(out, oracle(seqs, 4, n_hash))
 
 
+def test_pipelined_forms_on_a_caller_stream_and_from_two_host_threads(da, monkeypatch):
+    """the pipelined forms borrow side streams and events from a per-device pool: (a) the caller's stream is a non-default torch stream with
+    work queued ahead of the call, (b) two host threads call da_dev_similarity_mh on the same device at once with different inputs"""
+    import threading
+    import torch
+    from dynaalign_amd import device, synth
+    import dynaalign_amd as da_
+    monkeypatch.setenv("DYNAALIGN_PLANE_BITS", "12")
+    monkeypatch.setenv("DYNAALIGN_MH_PIPE_HEAD", "1")
+    monkeypatch.setenv("DYNAALIGN_MH_PIPE_STEP", "1")
+    sets = []
+    for seed in (1, 2):
+        rng = np.random.RandomState(seed)
+        base = sorted(set(synth.to_strings(*synth.h3n2_like(2600 + 400 * seed, 20))))
+        seqs = [base[i] for i in rng.randint(0, len(base), 6000 + 2 * seed)]
+        res, off = O.pack(seqs)
+        sets.append((seqs, device.DeviceSequences(np.asarray(res, np.uint8), np.asarray(off, np.int64))))
+    seeds = da_.hash_family_seeds(12345, 96)
+    want = [oracle(seqs, 4, 96) for seqs, _ in sets]
+    # (a)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        junk = torch.zeros(64 << 20, device="cuda")
+        for _ in range(20):
+            junk.add_(1.0)                                       # the call's first kernel has to queue behind these
+        out = device.similarity_mh(sets[0][1], 4, 96, seeds)
+        route = device.mh_last_route()
+    side.synchronize()
+    assert route["expansion"] == "rows, pipelined" and route["chunks"] >= 2
+    assert same(out.cpu().numpy(), want[0])
+    # (b)
+    results, errors = [None, None], []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                o = device.similarity_mh(sets[t][1], 4, 96, seeds)
+                torch.cuda.synchronize()
+                results[t] = (o.cpu().numpy(), device.mh_last_route())
+        except Exception as e:                                  # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(t,)) for t in (0, 1)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors
+    for t in (0, 1):
+        assert results[t][1]["expansion"] == "rows, pipelined"
+        assert same(results[t][0], want[t])
+
+
 def test_pipelined_form_needs_two_stages_of_twelve_planes(da, monkeypatch):
     """n_hash <= 32 (a single stage: the persistent compare does not take it) stays with the one-stream form"""
     from dynaalign_amd import synth
