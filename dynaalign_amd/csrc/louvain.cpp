@@ -27,7 +27,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -312,6 +314,8 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
   std::atomic<int32_t> decided(0), next_scan(0);              // positions finished by the decider / handed to helpers
   std::atomic<int> phase(0);                                  // 0 parked, 1 scanning, 2 quit
   std::atomic<int> pass_id(0), active(0);                     // pass counter; helpers inside their scanning loop
+  std::mutex park_m;                                          // parked helpers SLEEP on park_cv (they used to spin on yield() and took cores from the
+  std::condition_variable park_cv;                            // decider for the rest of a dense pass); phase / pass_id change under park_m when they wake helpers
   std::atomic<uint64_t> dbg_ns(0), dbg_cnt(0);                // (debug: time inside the helpers' scans)
   int32_t *comm_p = comm.data();
   std::vector<std::thread> helpers;
@@ -321,8 +325,13 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
       int done_pass = 0;
       for (;;) {
         int ph;
-        while ((ph = phase.load(std::memory_order_acquire)) != 2 && !(ph == 1 && pass_id.load(std::memory_order_acquire) != done_pass))
-          std::this_thread::yield();
+        {
+          std::unique_lock<std::mutex> lk(park_m);
+          park_cv.wait(lk, [&] {
+            ph = phase.load(std::memory_order_acquire);
+            return ph == 2 || (ph == 1 && pass_id.load(std::memory_order_acquire) != done_pass);
+          });
+        }
         if (ph == 2) return;
         active.fetch_add(1, std::memory_order_acq_rel);
         const int cur = pass_id.load(std::memory_order_acquire);
@@ -373,8 +382,12 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
       decided.store(0, std::memory_order_relaxed);
       next_scan.store(0, std::memory_order_relaxed);
       window.store(wmin, std::memory_order_relaxed);
-      pass_id.fetch_add(1, std::memory_order_acq_rel);
-      phase.store(1, std::memory_order_release);
+      {
+        std::lock_guard<std::mutex> lk(park_m);                 // (the resets above are ordered before the helpers' reads by this release + their acquire)
+        pass_id.fetch_add(1, std::memory_order_acq_rel);
+        phase.store(1, std::memory_order_release);
+      }
+      park_cv.notify_all();
     }
     for (int32_t idx = 0; idx < n; ++idx) {
       const int32_t v = order[(size_t)idx];
@@ -449,7 +462,11 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
     if (!(q_now > q_prev)) break;                               // igraph: keep passing only while modularity improves
     q_prev = q_now;
   }
-  phase.store(2, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(park_m);
+    phase.store(2, std::memory_order_release);
+  }
+  park_cv.notify_all();
   for (auto &h : helpers) h.join();
   // renumber in order of first appearance by vertex
   std::vector<int32_t> newid((size_t)n, -1);
