@@ -640,8 +640,10 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     // own float64 stores (27.2 ms): the route pays below f = 0.63
     take = U > 0 && U * 100 <= n * 60 && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
     if (take && (rc = launch_nw_dedup_build(d_res, d_off, n, U, p, stream, true)) != DA_OK) return rc;   // ids by first occurrence
-    if (take) {
-      // ub[b] = unique ids the input rows [0, 1024 b) use (prefix counts of the plan, read at the band boundaries): the pipelined form's schedule
+    const char *form0 = getenv("DYNAALIGN_MH_EXPAND");
+    const bool rows_form = (!form0 || !strcmp(form0, "rows") || !strcmp(form0, "rowspipe")) && expand_stream_ok(n, U, n_hash, d_out, ld);
+    if (take && !rows_form) {                                      // (the row expansion needs no schedule of output bands: one read-back less)
+      // ub[b] = unique ids the input rows [0, 1024 b) use (prefix counts of the plan, read at the band boundaries): the TILE pipeline's schedule
       const int64_t NB = mh_sym_bands(n);
       std::vector<int32_t> a((size_t)NB), b((size_t)NB);
       DA_HIP_TRY(hipMemcpy2DAsync(a.data(), 4, p.pm, 4096, 4, (size_t)NB, hipMemcpyDeviceToHost, stream));
@@ -732,8 +734,9 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       if (!pr) return fail(DA_ERR_HIP, "pipelined duplicate route: no side stream");
       struct PipeGuard { PipeRes *r; ~PipeGuard() { (void)hipStreamSynchronize(r->side); (void)hipStreamSynchronize(r->alt[0]); (void)hipStreamSynchronize(r->alt[1]); pipe_release(r); } } pguard{pr};
       hipEvent_t *pe = pr->ev.data();                                // per chunk: table rows done, rows begin / end; [3 C]: lists done
+      // beside the first band on the side stream: the table's diagonal / border tiles and the copy lists, both on the caller's stream
       DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
-      if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, pr->side)) != DA_OK) return rc;
+      if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, stream)) != DA_OK) return rc;
       if ((rc = launch_expand_stream_lists(p.uidx, n, U, lists.p, stream)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(pe[3 * C], stream));
       if (alt) { DA_HIP_TRY(hipStreamWaitEvent(pr->alt[0], pe[3 * C], 0)); DA_HIP_TRY(hipStreamWaitEvent(pr->alt[1], pe[3 * C], 0)); }

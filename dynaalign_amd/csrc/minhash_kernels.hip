@@ -182,13 +182,17 @@ struct TileId { int ti, tj; bool valid; };
 // Everything here is wave-uniform and runs while the other workgroups of the CU are in their
 // plane loops, so it is written to stay cheap: 32-bit integers, float estimates corrected by
 // exact integer tests, no 64-bit division, no double sqrt.  Needs ntiles < 2^31, T < 2^20.
-__device__ __forceinline__ int div_small(int l, int h) {   // l / h for 0 <= l < 2^24, 1 <= h <= 8
+__host__ __device__ __forceinline__ int div_small(int l, int h) {   // l / h for 0 <= l < 2^24, 1 <= h <= 8
+#ifdef __HIP_DEVICE_COMPILE__
   int q = (int)__fdividef((float)l, (float)h);
+#else
+  int q = (int)((float)l / (float)h);                                 // (host twin for tests: the estimate is corrected exactly either way)
+#endif
   while (q * h > l) --q;
   while ((q + 1) * h <= l) ++q;
   return q;
 }
-__device__ __forceinline__ TileId decode_tile(int64_t L, int TR, int T, bool symmetric) {
+__host__ __device__ __forceinline__ TileId decode_tile(int64_t L, int TR, int T, bool symmetric) {
   TileId o{0, 0, true};
   const int S = K2_BAND;
   if (!symmetric) {
@@ -1993,6 +1997,14 @@ int64_t mh_sym_band_prefix(int64_t n, int64_t band) {
   return band * c0 - (S * S / 2) * band * (band - 1);
 }
 int64_t mh_sym_bands(int64_t n) { return ceil_div(ceil_div(n, K2_TILE), K2_BAND); }
+// tests (host only, no device): the id range of a band, and decode_tile's host twin for one id
+extern "C" int64_t da_debug_sym_band_prefix(int64_t n, int64_t band) { return mh_sym_band_prefix(n, band); }
+extern "C" int da_debug_decode_sym_tile(int64_t L, int T, int *ti, int *tj) {
+  const TileId t = decode_tile(L, T, T, true);
+  if (ti) *ti = t.ti;
+  if (tj) *tj = t.tj;
+  return t.valid ? 1 : 0;
+}
 bool mh_compare_bands_ok(int64_t n, int n_hash, int plane_bits, const void *d_out, int64_t ld) {
   const int64_t T = ceil_div(n, K2_TILE);
   return plane_bits == 12 && n_hash > K2_GROUP && n_hash <= 65535 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&

@@ -221,3 +221,36 @@ def test_duplicate_route_entry_points_reject_bad_arguments(lib):
     assert lib.da_dev_expand_workspace_bytes(100000, 45000, 0, 500, 0) == 45000 * 100000 * 2
     assert lib.da_dev_expand_workspace_bytes(100000, 70000, 0, 500, 0) == 256              # > 65536 unique strings: no fast passes
     assert lib.da_dev_unique_rows_bytes(100001, 10) == 10 * 100008 * 2
+
+
+def test_band_ranges_of_the_symmetric_tile_numbering():
+    """host logic of the pipelined duplicate route (minhash_kernels.hip mh_sym_band_prefix / decode_tile, run on the host): the symmetric
+    tiles are numbered band by band (8 tile rows), so that [prefix(b), prefix(b + 1)) is exactly band b's tiles right of or on the diagonal --
+    every tile once, every id valid -- for full bands and a partial last band"""
+    import ctypes
+    from dynaalign_amd import _capi
+    lib = _capi.load()
+    lib.da_debug_sym_band_prefix.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    lib.da_debug_sym_band_prefix.restype = ctypes.c_int64
+    lib.da_debug_decode_sym_tile.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.da_debug_decode_sym_tile.restype = ctypes.c_int
+    for n in (1, 127, 128, 129, 1024, 1025, 3000, 5 * 1024 + 7, 16 * 1024, 44931):
+        T = -(-n // 128)
+        bands = -(-T // 8)
+        assert lib.da_debug_sym_band_prefix(n, 0) == 0 and lib.da_debug_sym_band_prefix(n, bands) == T * (T + 1) // 2
+        assert lib.da_debug_sym_band_prefix(n, bands + 3) == T * (T + 1) // 2
+        seen = set()
+        ti, tj = ctypes.c_int(0), ctypes.c_int(0)
+        for b in range(bands):
+            lo, hi = lib.da_debug_sym_band_prefix(n, b), lib.da_debug_sym_band_prefix(n, b + 1)
+            rows = min(8, T - 8 * b)
+            assert hi - lo == sum(T - r for r in range(8 * b, 8 * b + rows))
+            step = 1 if T <= 64 else 37                      # every id of the small cases, a stride through the large ones
+            for L in sorted(set(range(lo, hi, step)) | {hi - 1}):
+                assert lib.da_debug_decode_sym_tile(L, T, ctypes.byref(ti), ctypes.byref(tj)) == 1
+                assert 8 * b <= ti.value < 8 * b + rows and ti.value <= tj.value < T
+                if step == 1:
+                    assert (ti.value, tj.value) not in seen
+                    seen.add((ti.value, tj.value))
+        if T <= 64:
+            assert len(seen) == T * (T + 1) // 2
