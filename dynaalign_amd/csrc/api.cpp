@@ -638,7 +638,11 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     route.unique = U;
     // K2 on U rows + column gather + expansion (0.5 + 1.6 f + 22 f^2 + 4.1 f + 14.4 ms at N = 100k, f = U / n) against K1 + K1b + K2 with its
     // own float64 stores (27.2 ms): the route pays below f = 0.63
-    take = U > 0 && U * 100 <= n * 60 && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
+    // ... with the tile expansion.  With the row expansion (no gather, no copy of the table) the route costs ~1.5 + 26 f^2 + 14 ms one kernel after the
+    // other: 24.4 ms at f = 0.60, 26.6 at f = 0.65 against 27 (12 code planes) - 30 ms (14) for the direct kernels (profiles/r03_q_dedup_threshold.txt): 0.68
+    int64_t max_pct = expand_stream_ok(n, std::min<int64_t>(U, 65536), n_hash, d_out, ld) ? 68 : 60;
+    if (const char *e = getenv("DYNAALIGN_MH_DEDUP_MAX_PCT")) max_pct = atoll(e);
+    take = U > 0 && U * 100 <= n * max_pct && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
     if (take && (rc = launch_nw_dedup_build(d_res, d_off, n, U, p, stream, true)) != DA_OK) return rc;   // ids by first occurrence
     const char *form0 = getenv("DYNAALIGN_MH_EXPAND");
     const bool rows_form = (!form0 || !strcmp(form0, "rows") || !strcmp(form0, "rowspipe")) && expand_stream_ok(n, U, n_hash, d_out, ld);

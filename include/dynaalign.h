@@ -215,7 +215,7 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
  * n x n matrix in HBM (d_out, leading dimension ld >= n doubles; 16-byte aligned and even ld for the wide-store kernels).
  * Byte-identical sequences have identical signatures, so -- like da_dev_nw -- the call first collapses them: signatures,
  * dictionary codes and the compare run on the U unique strings (K2's work shrinks by (U/n)^2) and the n x n matrix is an
- * index expansion of the U x U count table in two streaming passes.  Exact; taken when U <= 0.6 n (below that K2's saving
+ * index expansion of the U x U count table.  Exact; taken when U <= 0.68 n (0.6 n when only the tile expansion applies; below that K2's saving
  * outweighs the expansion), n >= 2048, U <= 65536, n_hash <= 2047; otherwise the three kernels run on all n rows (what uniform peptides
  * get).  Allocates its intermediates itself (parked between calls, da_release_device_memory frees them) and synchronises
  * the stream.  DYNAALIGN_MH_NO_DEDUP=1 disables the route.  da_mh_last_route reports what the calling thread's last such
