@@ -123,7 +123,8 @@ def test_h3n2_like_12000_properties(da):
 @pytest.mark.parametrize("pool,n,n_hash,env", [(3000, 8000, 100, {"DYNAALIGN_MH_PIPE_STEP": "1"}),
                                                (3000, 8000, 100, {"DYNAALIGN_MH_PIPE_STEP": "1", "DYNAALIGN_MH_PIPE_ONE_STREAM": "1"}),
                                                (4200, 9000, 64, {"DYNAALIGN_MH_PIPE_WG": "1"}), (2500, 5000, 33, {"DYNAALIGN_MH_PIPE_WG": "4", "DYNAALIGN_MH_PIPE_STEP": "2"}),
-                                               (2000, 2600, 500, {"DYNAALIGN_MH_PIPE_STEP": "1"})])
+                                               (2000, 2600, 500, {"DYNAALIGN_MH_PIPE_STEP": "1"}),
+                                               (3000, 8000, 600, {"DYNAALIGN_MH_PIPE_STEP": "1"})])     # 10-bit counts: the unpacked LDS row, one K2 ring beside it
 def test_pipelined_form_equals_one_stream_form_and_oracle(da, monkeypatch, pool, n, n_hash, env):
     """api.cpp "PIPELINED form": the unique table compared band by band on a side stream while finished output row bands are gathered
     and expanded -- several chunks (U > 1024), every schedule switch; bit-identical to the one-stream form and the oracle
