@@ -247,6 +247,45 @@ def test_expansion_forms_on_awkward_sets(da, small_n_route, monkeypatch, form):
         assert same(buf[:, :n].cpu().numpy(), oracle(seqs, 4, n_hash)) and bool((buf[:, n] == -1.0).all())
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_expansion_forms_on_random_sets(da, small_n_route, monkeypatch, case):
+    """seeded random sets through every form of the duplicate route's expansion against the oracle (reference src/minHash.cpp:119-188): random
+    size (even and odd), duplicate share, copy distribution (a few heavy strings), ragged lengths, and n_hash at the switches of the row
+    expansion -- 33 (two stages: the banded compare's minimum), 511 / 512 (packed / unpacked LDS row), 2047 (its maximum)"""
+    import torch
+    from dynaalign_amd import device
+    import dynaalign_amd as da_
+    rng = np.random.RandomState(1000 + case)
+    n_hash = [33, 64, 511, 512, 513, 2047, 100, 500][case % 8]
+    n = int(rng.randint(300, 1400 if n_hash > 600 else 2600))
+    n_unique = int(n * rng.uniform(0.15, 0.6))
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    pool = sorted({"".join(map(chr, alpha[rng.randint(0, 20, rng.randint(0, 33))])) for _ in range(n_unique)})
+    heavy = rng.randint(0, len(pool), 3)
+    picks = np.where(rng.uniform(size=n) < 0.25, heavy[rng.randint(0, 3, n)], rng.randint(0, len(pool), n))
+    seqs = [pool[i] for i in picks]
+    if len(set(seqs)) * 100 > n * 60:
+        seqs = seqs[: n // 2] * 2                                   # keep the duplicate route's own rule satisfied
+        n = len(seqs)
+    res, off = O.pack(seqs)
+    ds = device.DeviceSequences(np.asarray(res, np.uint8), np.asarray(off, np.int64))
+    seeds = da_.hash_family_seeds(4242 + case, n_hash)
+    want = oracle(seqs, 3, n_hash, seed=4242 + case)
+    monkeypatch.setenv("DYNAALIGN_PLANE_BITS", "12")
+    monkeypatch.setenv("DYNAALIGN_MH_PIPE_HEAD", "1")
+    monkeypatch.setenv("DYNAALIGN_MH_PIPE_STEP", "1")
+    ld = n + (n & 1)
+    for form in ("rowspipe", "rows", "pipe", "tiles"):
+        monkeypatch.setenv("DYNAALIGN_MH_EXPAND", form)
+        buf = torch.full((n, ld + 2), -1.0, dtype=torch.float64, device="cuda")
+        device.similarity_mh(ds, 3, n_hash, seeds, out=buf[:, :n])
+        route = device.mh_last_route()
+        assert route["dedup"] and route["unique"] == len(set(seqs)), (form, route)
+        assert route["expansion"].startswith("rows" if form.startswith("rows") else "tiles"), (form, route)
+        assert same(buf[:, :n].cpu().numpy(), want), (form, n, n_hash)
+        assert bool((buf[:, n:] == -1.0).all())
+
+
 def test_row_expansion_quotient_equals_the_divide_for_every_count(da):
     """k_expand_stream forms count / n_hash as RN(q0 + (c - q0 n) r), r = RN(1 / n), q0 = RN(c r) (minhash_kernels.hip es_ratio) instead of
     dividing (src/minHash.cpp:174): the same double for EVERY 0 <= c <= n_hash, n_hash = 1 .. 2047 and a few larger -- run on the device"""
