@@ -934,6 +934,80 @@ __global__ __launch_bounds__(1024) void k_dd_scan_pair(const int32_t *__restrict
   }
   if (tid == 0) { pm[n] = (int32_t)(uint32_t)carry_s; ps[n] = (int32_t)(uint32_t)(carry_s >> 32); }
 }
+// The same two scans over many workgroups (n >= 8192): block sums, a scan of the block sums by one workgroup, then every block's own exclusive scan plus
+// its offset -- three short launches (~0.03 ms) instead of one workgroup walking the whole array (0.15 ms at n = 100k: the plan sits in front of everything).
+// MODE 0: (fm, fs) -> (pm, ps) packed in 64 bits;  MODE 1: in (int32) -> out (int64)
+template <int MODE>
+__device__ __forceinline__ uint64_t dd_scan_load(const int32_t *a, const int32_t *b, int32_t i) {
+  if (MODE == 0) return (uint64_t)(uint32_t)a[i] | ((uint64_t)(uint32_t)b[i] << 32);
+  return (uint64_t)(int64_t)a[i];
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_dd_scan_sums(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int32_t n, uint64_t *__restrict__ bsum) {
+  __shared__ uint64_t wsum[16];
+  const int32_t i = blockIdx.x * 1024 + threadIdx.x;
+  uint64_t x = i < n ? dd_scan_load<MODE>(a, b, i) : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint64_t t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; bsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_dd_scan_offsets(uint64_t *__restrict__ bsum, int32_t nblocks) {   // in place: exclusive scan; bsum[nblocks] = total
+  __shared__ uint64_t wsum[16];
+  __shared__ uint64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int32_t base = 0; base < nblocks; base += 1024) {
+    const int32_t i = base + tid;
+    const uint64_t v = i < nblocks ? bsum[i] : 0;
+    uint64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint64_t carry = carry_s;
+    if (i < nblocks) bsum[i] = carry + woff + x - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) bsum[nblocks] = carry_s;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_dd_scan_apply(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int32_t n, const uint64_t *__restrict__ bsum,
+                                                        int32_t *__restrict__ o0, int32_t *__restrict__ o1, int64_t *__restrict__ o64) {
+  __shared__ uint64_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t i = blockIdx.x * 1024 + tid;
+  const uint64_t v = i < n ? dd_scan_load<MODE>(a, b, i) : 0;
+  uint64_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint64_t woff = bsum[blockIdx.x];
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  const uint64_t e = woff + x - v;
+  if (i < n) {
+    if (MODE == 0) { o0[i] = (int32_t)(uint32_t)e; o1[i] = (int32_t)(uint32_t)(e >> 32); }
+    else o64[i] = (int64_t)e;
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    const uint64_t t = bsum[gridDim.x];
+    if (MODE == 0) { o0[n] = (int32_t)(uint32_t)t; o1[n] = (int32_t)(uint32_t)(t >> 32); }
+    else o64[n] = (int64_t)t;
+  }
+}
 __global__ __launch_bounds__(256) void k_dd_assign(const int32_t *__restrict__ rep, const int32_t *__restrict__ mult,
                                                    const int32_t *__restrict__ last, const int32_t *__restrict__ pm,
                                                    const int32_t *__restrict__ ps, const int64_t *__restrict__ off, int32_t n,
@@ -1009,7 +1083,15 @@ int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t 
   hipLaunchKernelGGL(k_dd_insert, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1);
   hipLaunchKernelGGL(k_dd_lookup, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1, p.rep, p.mult, p.last);
   hipLaunchKernelGGL(k_dd_flags, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, (int32_t)n, p.fm, p.fs);
-  hipLaunchKernelGGL(k_dd_scan_pair, dim3(1), dim3(1024), 0, stream, p.fm, p.fs, p.pm, p.ps, (int32_t)n);
+  const bool wide_scan = !getenv("DYNAALIGN_PLAN_SCAN_ONE_WG");   // (diagnostic switch: the single-workgroup scans)
+  if (n >= 8192 && wide_scan) {     // (the hash table is free again after k_dd_lookup: its words hold the block sums)
+    const int32_t nblk = (int32_t)ceil_div(n, 1024);
+    uint64_t *bsum = reinterpret_cast<uint64_t *>(p.table);
+    hipLaunchKernelGGL(k_dd_scan_sums<0>, dim3((unsigned)nblk), dim3(1024), 0, stream, p.fm, p.fs, (int32_t)n, bsum);
+    hipLaunchKernelGGL(k_dd_scan_offsets, dim3(1), dim3(1024), 0, stream, bsum, nblk);
+    hipLaunchKernelGGL(k_dd_scan_apply<0>, dim3((unsigned)nblk), dim3(1024), 0, stream, p.fm, p.fs, (int32_t)n, bsum, p.pm, p.ps, (int64_t *)nullptr);
+  } else
+    hipLaunchKernelGGL(k_dd_scan_pair, dim3(1), dim3(1024), 0, stream, p.fm, p.fs, p.pm, p.ps, (int32_t)n);
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
@@ -1020,7 +1102,15 @@ int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t 
   hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, p.last, p.pm, p.ps, d_off, (int32_t)n, p.uid_of,
                      p.ufirst, p.ulast, p.ulen, first_order ? 1 : 0);
   hipLaunchKernelGGL(k_dd_map, dim3(nb), dim3(256), 0, stream, p.rep, p.uid_of, (int32_t)n, p.uidx);
-  hipLaunchKernelGGL(k_dd_scan<int64_t>, dim3(1), dim3(1024), 0, stream, p.ulen, p.uoff, (int32_t)U);
+  if (U >= 8192 && !getenv("DYNAALIGN_PLAN_SCAN_ONE_WG")) {
+    const int32_t nblk = (int32_t)ceil_div(U, 1024);
+    uint64_t *bsum = reinterpret_cast<uint64_t *>(p.table);
+    hipLaunchKernelGGL(k_dd_scan_sums<1>, dim3((unsigned)nblk), dim3(1024), 0, stream, p.ulen, (const int32_t *)nullptr, (int32_t)U, bsum);
+    hipLaunchKernelGGL(k_dd_scan_offsets, dim3(1), dim3(1024), 0, stream, bsum, nblk);
+    hipLaunchKernelGGL(k_dd_scan_apply<1>, dim3((unsigned)nblk), dim3(1024), 0, stream, p.ulen, (const int32_t *)nullptr, (int32_t)U, bsum, (int32_t *)nullptr,
+                       (int32_t *)nullptr, p.uoff);
+  } else
+    hipLaunchKernelGGL(k_dd_scan<int64_t>, dim3(1), dim3(1024), 0, stream, p.ulen, p.uoff, (int32_t)U);
   hipLaunchKernelGGL(k_dd_gather, dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, stream, d_codes, d_off, p.ufirst, p.uoff, (int32_t)U, p.ucodes);
   hipLaunchKernelGGL(k_dd_blocks, dim3((unsigned)ceil_div(U, 64)), dim3(64), 0, stream, p.ufirst, p.ulast, (int32_t)U, p.minfirst, p.maxlast);
   DA_HIP_TRY(hipGetLastError());
