@@ -171,16 +171,138 @@ def pmc_traffic(kernel, n):
     return None
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def visible_devices():
+    """number of GPUs this process could open; torch.cuda.device_count() does not initialise the GPU on this image, so the
+    launching parent may ask"""
+    import torch
+    return torch.cuda.device_count()
+
+
+def launch_ranks(n_ranks, argv, child_cmd=None, device_count=visible_devices, timeout_s=None, out=None, err=None):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves.
+
+    The parent never touches a GPU (build() is CPU-only; counting devices does not initialise HIP here) and never replaces
+    itself: it starts N fresh child processes -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT set, the same arguments -- relays rank 0's stdout (its last JSON line is the parent's last stdout line) and the
+    other ranks' stderr, and returns non-zero when ANY child does, when a child outlives `timeout_s`, or when rank 0 printed no
+    JSON line.  With the nccl (= RCCL) backend fewer than N visible devices is an error: never a silent fall-back to fewer GPUs.
+    Returns the exit code."""
+    import threading
+    out = out or sys.stdout
+    err = err or sys.stderr
+    backend = os.environ.get("DYNAALIGN_BENCH_BACKEND", "nccl")
+    if n_ranks < 2:
+        raise ValueError("launch_ranks is for N > 1")
+    if backend == "nccl":
+        ndev = device_count()
+        if ndev < n_ranks:
+            print("[bench] --gpus %d needs %d visible GPUs with the RCCL backend, this node shows %d: not starting "
+                  "(DYNAALIGN_BENCH_BACKEND=gloo rehearses the code path with ranks sharing the visible devices; it is not a measurement)"
+                  % (n_ranks, n_ranks, ndev), file=err)
+            return 3
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("DYNAALIGN_BENCH_LAUNCH_TIMEOUT", "2400"))
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
+    port = free_port()
+    procs, pumps, rank0_lines = [], [], []
+
+    def pump(stream, sink, keep=None, prefix=""):
+        for raw in iter(stream.readline, b""):
+            text = raw.decode("utf-8", "replace")
+            if keep is not None:
+                keep.append(text)
+            else:
+                sink.write(prefix + text)
+                sink.flush()
+        stream.close()
+
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DYNAALIGN_BENCH_BUILT="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                             stderr=subprocess.PIPE)
+        procs.append(p)
+        if r == 0:
+            pumps.append(threading.Thread(target=pump, args=(p.stdout, None, rank0_lines), daemon=True))
+        pumps.append(threading.Thread(target=pump, args=(p.stderr, err, None, "" if r == 0 else "[rank %d] " % r), daemon=True))
+    for t in pumps:
+        t.start()
+
+    def stop_all():
+        for p in procs:                      # exactly the processes started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    pending = set(range(n_ranks))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if 0 < code < 256 else 1
+                    print("[bench] rank %d exited with %d: stopping the other ranks" % (r, code), file=err)
+                    stop_all()
+        if pending and time.monotonic() > deadline:
+            print("[bench] ranks %s still running after %.0f s: stopping them" % (sorted(pending), timeout_s), file=err)
+            stop_all()
+            rc = rc or 124
+            break
+        if pending:
+            time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    for t in pumps:
+        t.join(5)
+    json_line = None
+    for text in rank0_lines:
+        s = text.strip()
+        if s.startswith("{") and s.endswith("}"):
+            json_line = s
+        else:
+            out.write(text)
+    if rc == 0 and json_line is None:
+        print("[bench] rank 0 printed no result line", file=err)
+        rc = 1
+    if json_line is not None and rc == 0:
+        out.write(json_line + "\n")
+    elif json_line is not None:
+        print("[bench] a rank failed; rank 0's line is NOT a result: " + json_line[:400], file=err)
+    out.flush()
+    return rc
+
+
 def main():
     a = parse()
     import __graft_entry__ as g
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # no launcher around us: become one (never a silent 1-GPU run under `--gpus N`)
+        g.build()
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and a.gpus != world:
+    if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if local_rank == 0:
+    if local_rank == 0 and not os.environ.get("DYNAALIGN_BENCH_BUILT"):
         g.build()                       # a no-op when the in-tree .so files are current; before anything touches the GPU
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -188,14 +310,23 @@ def main():
     # DYNAALIGN_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (the ranks share
     # the visible devices, the exchange goes through the host) -- never a measurement
     backend = os.environ.get("DYNAALIGN_BENCH_BACKEND", "nccl")
-    ndev = max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (backend == "nccl" and world > 1 and local_rank >= ndev):
+        raise SystemExit("[bench] rank %d (local %d of %d): %d visible GPUs -- a rank per GPU is required with the RCCL backend"
+                         % (rank, local_rank, world, ndev))
     torch.cuda.set_device(local_rank % ndev if backend != "nccl" else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a finite rendezvous / collective timeout: a rank that never arrives or an RCCL error ends the run with a non-zero exit
+        # (torch's watchdog aborts the process on a timed-out or failed collective), not with a hang
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        tmo = datetime.timedelta(seconds=float(os.environ.get("DYNAALIGN_BENCH_DIST_TIMEOUT", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (a.gpus, dist.get_world_size()))
         dist.barrier()
     import dynaalign_amd as da
     from dynaalign_amd import _capi, device, sharding, synth
@@ -449,7 +580,7 @@ def main():
     main_roof["step_algorithmic_bytes"] = step_bytes
     line = {
         "metric": "sequence-pairs/sec (MinHash k=4 n_hash=500; NW BLOSUM62) at 1/2/4/8 MI355X",
-        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "pairs/s", "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic" if os.environ.get("DYNAALIGN_BENCH_BACKEND", "nccl") == "nccl" else "synthetic; REHEARSAL over %s, not a measurement" % os.environ["DYNAALIGN_BENCH_BACKEND"],
         "boundary": "T_k: kernels only, packed residues and the dense f64 result resident in HBM" if world == 1 else

@@ -370,50 +370,120 @@ def test_nw_too_long_sequences_fail_loudly(da):
 
 # ---------------------------------------------------------------- BASELINE sizes (properties)
 
-def test_mh_10k_properties_and_sampled_rows(da):
-    """config 2: 10k synthetic 20-mers, k=4, n_hash=500.  Full oracle compare of a row slice,
-    plus symmetry / diagonal / value-set properties on the whole matrix."""
+def _workload_10k(name):
     from dynaalign_amd import synth
-    res, off = synth.uniform_peptides(10000, 20, seed=7)
-    seqs = synth.to_strings(res, off)
-    M = np.asarray(da.similarityMH(seqs, 4, 500, seed=12345))
-    assert M.shape == (10000, 10000)
-    assert np.array_equal(M, M.T)
-    assert np.all(np.diag(M) == 1.0)
-    cnt = M * 500
-    assert np.array_equal(cnt, np.round(cnt)) and cnt.min() >= 0 and cnt.max() <= 500
-    seeds = da.hash_family_seeds(12345, 500)
-    sig = O.signatures(seqs, 4, 500, seeds)
-    assert np.array_equal(da.minhash_signatures(seqs, 4, 500, seed=12345), sig)   # bit-exact signatures
-    for r0 in (0, 4993, 9900):
-        want = O.mh_counts(sig, r0, r0 + 100).astype(np.float64) / 500
-        assert_same_f64(M[r0:r0 + 100], want)
-    # checksum of the WHOLE count matrix that never walks the pair loop:
-    #   sum_ij matches(i,j) = sum_h sum_v (number of sequences whose sig[.,h] == v)^2
-    total = 0
-    for h in range(500):
-        _, c = np.unique(sig[:, h], return_counts=True)
-        total += int((c.astype(np.int64) ** 2).sum())
-    sub = da.mh_counts(seqs, 4, 500, seed=12345)
-    assert sub.shape == (10000, 10000)
-    assert int(sub.astype(np.int64).sum()) == total
-    assert np.array_equal(sub.astype(np.float64) / 500, M)
+    res, off = (synth.uniform_peptides(10000, 20, seed=7) if name == "uniform" else synth.h3n2_like(10000, 20))
+    return res, off, synth.to_strings(res, off)
 
 
-def test_nw_10k_sampled_rows(da):
-    """config 3: 10k synthetic 20-mers, BLOSUM62 full N x N: oracle compare on row slices
-    (the CPU oracle needs ~16 us/pair) + symmetry/diagonal/range properties."""
-    from dynaalign_amd import synth
-    res, off = synth.uniform_peptides(10000, 20, seed=7)
-    seqs = synth.to_strings(res, off)
+class _env:
+    """route switches of the library, for the duration of a call"""
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("workload", ["uniform", "h3n2like"])
+def test_mh_10k_whole_matrix_against_the_oracle(da, workload):
+    """BASELINE config 2 (10k synthetic 20-mers, k=4, n_hash=500), nothing sampled: the ENTIRE 10 000 x 10 000 float64 result of the
+    reference-boundary call and of every route of the device call (direct kernels, duplicate route, sparse route) against the oracle's
+    similarityMH bit for bit (src/minHash.cpp:160-178), all signatures, and all 10^8 uint16 match counts against the oracle's compare
+    loop run on the ORACLE's signatures."""
+    import torch
+    from dynaalign_amd import device
+    res, off, seqs = _workload_10k(workload)
+    n, k, n_hash = 10000, 4, 500
+    seeds = da.hash_family_seeds(12345, n_hash)
+    rc, want = O.similarity_mh(seqs, k, n_hash, seeds)                       # the oracle's whole call
+    assert rc == 0
+    wb = bits(want)
+    osig = O.signatures(seqs, k, n_hash, seeds)
+    ocnt = O.mh_counts(osig)                                                 # [n][n] uint16, diagonal = n_hash
+    assert np.array_equal(bits(ocnt.astype(np.float64) / n_hash), wb)        # the oracle agrees with itself (count / n_hash IS the matrix)
+
+    assert np.array_equal(da.minhash_signatures(seqs, k, n_hash, seed=12345), osig)
+    assert np.array_equal(da.mh_counts(seqs, k, n_hash, seed=12345), ocnt)
+    M = np.asarray(da.similarityMH(seqs, k, n_hash, seed=12345))             # what R sees (host-pointer boundary)
+    assert M.shape == (n, n) and np.array_equal(bits(M), wb)
+    del M
+
+    ds = device.DeviceSequences(res, off)
+    routes = {}
+
+    def dev_call(**env):
+        with _env(**env):
+            out = device.similarity_mh(ds, k, n_hash, seeds)
+            torch.cuda.synchronize()
+        r = device.mh_last_route()
+        got = out.cpu().numpy()
+        del out
+        assert np.array_equal(bits(got), wb), "route %s differs from the oracle" % (r,)
+        return r
+    r = dev_call()                                                           # the route the library picks by itself
+    routes["default"] = r
+    r = dev_call(DYNAALIGN_MH_NO_DEDUP=1, DYNAALIGN_MH_NO_SPARSE=1)
+    assert not r["dedup"] and not r["sparse"]
+    if workload == "uniform":
+        assert routes["default"]["sparse"], routes                           # uniform 10k: signatures rarely agree -> sparse route
+    else:
+        assert routes["default"]["dedup"], routes                            # h3n2-like 10k: duplicates collapsed
+        for form in ("rows", "tiles", "pipe", "rowspipe"):                    # every expansion form of the duplicate route
+            r = dev_call(DYNAALIGN_MH_EXPAND=form)
+            assert r["dedup"], (form, r)
+    # device compare in its uint16 form on the planes (what the sharded / edge paths consume)
+    sig, planes = device.minhash_signatures(ds, k, n_hash, seeds)
+    assert np.array_equal(sig[:, :n_hash].cpu().numpy().view(np.uint32), osig)
+    from dynaalign_amd import _capi
+    cnt = device.mh_compare(planes, n, n_hash, kind=_capi.DA_OUT_COMPACT)
+    assert np.array_equal(cnt.cpu().numpy().view(np.uint16), ocnt)
+
+
+@pytest.mark.parametrize("workload", ["uniform", "h3n2like"])
+def test_nw_10k_whole_matrix_against_the_oracle(da, workload):
+    """BASELINE config 3 (10k synthetic 20-mers, BLOSUM62 / 10 / 4, full N x N), nothing sampled: (matches, length, score) of all 10^8
+    ordered elements against the oracle's DP + traceback (src/pairwiseSeqAlign.cpp:209-313 under the driver's calc(seq[min], seq[max]),
+    :340-352), and the float64 ratio matrix as uint64 -- through the host-pointer call and through the device call's direct and
+    duplicate routes."""
+    import torch
+    from dynaalign_amd import device, _capi
+    res, off, seqs = _workload_10k(workload)
+    n = 10000
+    rc, omt, oln, osc, _ = O.nw_rows(seqs, 0, n)                             # OpenMP over rows: ~10 s on the box's 16 threads
+    assert rc == 0
+    want = omt / oln.astype(np.float64)
+    wb = bits(want)
     W = np.asarray(da.similarityNW(seqs))
-    assert W.shape == (10000, 10000)
-    assert np.array_equal(W, W.T) and np.all(np.diag(W) == 1.0)
-    assert W.min() >= 0.0 and W.max() <= 1.0
-    for r0 in (0, 5000, 9990):
-        rc, mt, ln, sc, _ = O.nw_rows(seqs, r0, r0 + 10)
-        assert rc == 0
-        assert_same_f64(W[r0:r0 + 10], mt / ln.astype(np.float64))
+    assert W.shape == (n, n) and np.array_equal(bits(W), wb)
+    del W
+    half = n // 2                                                            # integers in two row blocks (3 x 200 MB each)
+    for r0 in (0, half):
+        mt, ln, sc = da.nw_pairs(seqs, row_begin=r0, row_end=r0 + half)
+        assert np.array_equal(mt, omt[r0:r0 + half]) and np.array_equal(ln, oln[r0:r0 + half]) and np.array_equal(sc, osc[r0:r0 + half])
+    ds = device.DeviceSequences(res, off)
+    assert int(device.nw_encode(ds).item()) == 0
+    seen = set()
+    for env in ({}, {"DYNAALIGN_NW_NO_DEDUP": 1}, {"DYNAALIGN_NW_DEDUP_MIN_N": 1}):
+        with _env(**env):
+            out = device.nw(ds, "BLOSUM62", 10, 4, 0, n, True, _capi.DA_OUT_F64)
+            torch.cuda.synchronize()
+        r = device.nw_last_route()
+        seen.add(bool(r["dedup"]))
+        assert np.array_equal(bits(out.cpu().numpy()), wb), "NW route %s differs from the oracle" % (r,)
+        del out
+    if workload == "h3n2like":
+        assert seen == {True, False}                                         # both the duplicate route and the direct kernel were hit
 
 
 def test_100k_headline_workload_properties(da):

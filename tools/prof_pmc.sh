@@ -6,6 +6,7 @@
 set -e
 TAG=${1:-pmc}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -44,12 +45,12 @@ import json
 n = 100000
 argv = os.environ.get("BENCH_ARGS", "").split()
 if "--n" in argv: n = int(argv[argv.index("--n") + 1])
-sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tools"))
-try:
-    import source_hash
-    src_hash = source_hash.source_hash()
-except Exception:
-    src_hash = None
+# the hash ties this profile to the build it was taken on (bench.py reports PMC traffic only from a profile of the running sources):
+# a profile without it is useless, so fail loudly rather than record null
+sys.path.insert(0, os.path.join(os.environ["ROOT"], "tools"))
+import source_hash
+src_hash = source_hash.source_hash()
+assert src_hash, "source hash not computed"
 json.dump({"n": n, "source_hash": src_hash, "bench_args": os.environ.get("BENCH_ARGS", ""), "note": "rocprofv3 --pmc, one pass per counter group; "
            "values are per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-counts wide reads 2x on gfx950)",
            "kernels": {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}},
