@@ -410,7 +410,11 @@ int da_abi_version(void) { return DA_ABI_VERSION; }
 
 size_t da_release_device_memory(void) {
   (void)da::destroy_cached_comms();          // cached RCCL communicators (multi-device entry points) go too
+#ifdef DA_K2_EXPERIMENTS
   return big_cache().release(-1) + da::release_compare_scratch();
+#else
+  return big_cache().release(-1);
+#endif
 }
 
 int da_device_count(void) {

@@ -891,476 +891,9 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
 #undef K2P_STAMP
 }
 
-// ---- ROLE-SPLIT persistent 12-plane compare, float64 output (round 3) ---------------------------------------------------
-// What the measurements of rounds 1-2 said: the plane loop runs at the VALU issue bound (19.7-20.3 ms at N = 100k without its
-// stores, profiles/r02_i_*), the 80 GB of float64 stores need ~13 ms of the CUs' store paths, and issued by the computing waves
-// they cost 5 ms on top (a storing wave does not compute, and the loop needs every resident wave to hide its LDS latencies).
-// Round 3 measured two more facts (profiles/r03_a_*): three resident compute workgroups per CU run the loop as fast as four
-// (19.9 vs 20.1 ms without stores), and ONE workgroup per CU saturates the CU's store path (tools/ubench/corun: 6.2 TB/s; a
-// store role at wave priority 3 beside three VALU-bound workgroups costs the latter 8 %).  So the fourth workgroup slot of every
-// CU becomes a STORE role:
-//   compute role (3 per CU)  k_mh_compare_p12's tile loop (same generated block, tile ids from a per-XCD counter); the lane's 32
-//                            packed counters go to the workgroup's MAILBOX in global memory -- 8 coalesced 16-byte stores per
-//                            lane and tile (32 KiB, L2-resident) instead of 64 float64 stores;
-//   store role (1 per CU)    polls the mailboxes of its CU's compute workgroups, takes a tile's counters into the registers of the
-//                            same lanes and runs the float64 epilogue (table lookups + 64 streaming 16-byte stores, direct +
-//                            mirrored) at wave priority 3.
-// Roles are chosen per physical CU (HW_ID + XCC_ID -> a ticket: the last of the `occ` workgroups that fit a CU stores).  A
-// mailbox has R12_RING slots; a compute workgroup that finds its mailbox full stores the tile ITSELF (the p12 epilogue), so no
-// role ever waits for another: correctness and termination do not depend on which workgroups are resident.  The store role
-// leaves when every tile is accounted for (tiles_done == n_taken).  Memory ordering without bulk cache maintenance: mailbox
-// data and flags use agent-scope (sc1) accesses; a tile is published only after the NEXT tile's block has run, whose counted
-// vmcnt waits (in order) and stage barriers imply that every wave's mailbox stores have completed.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-constexpr int R12_RING = 4;                  // mailbox slots per compute workgroup
-constexpr int R12_MAX_MBOX = 4096;
-constexpr int R12_TABLE = 504;               // doubles of the count -> ratio table (n_hash <= 503): ring 36 KiB + table + 64 B = 40 KiB
-constexpr int R12_TILE_UNITS = 8 * K2_THREADS;   // 16-byte units of one mailbox slot: [8][256]
-struct R12Ctl {
-  unsigned n_taken, tiles_done, n_mbox, slow_tiles, pad[28];   // (k_r12_setup / da_debug_k2_roles_stats read the first four)
-  unsigned next[8][32];                      // per logical XCD: tile ids handed out (relative to the XCD's id range); one 128-byte line each
-  unsigned exhausted[8][32];                 // ... set once the XCD's range has run out (what the pollers read: never the hot counters)
-  unsigned cu_tickets[2048];                 // workgroups that arrived on a CU (key: XCC id | SE / SH / CU id)
-  unsigned mbox_of[2048][4];                 // mailbox id + 1 of the CU's compute workgroups, by ticket
-  unsigned published[R12_MAX_MBOX], consumed[R12_MAX_MBOX];
-  unsigned tile_of[R12_MAX_MBOX][R12_RING];
-};
-__device__ __forceinline__ unsigned r12_cu_key() {
-  unsigned hw, xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  return ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
-}
-__device__ __forceinline__ unsigned r12_ld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void r12_st(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void r12_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS hand-over only: no vmcnt drain
-
-// k_r12_setup: zero the control block, count the tiles the role-split kernel takes
-__global__ __launch_bounds__(256) void k_r12_setup(R12Ctl *ctl, int64_t n, int64_t ld, const void *out, int64_t ntiles, int T) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool take = false;
-  if (i < ntiles) {
-    const TileId t = decode_tile(i, T, T, true);
-    take = t.valid && a12_takes(t.ti, t.tj, n, ld, out, true);
-  }
-  const unsigned long long m = __ballot(take);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&ctl->n_taken, (unsigned)__popcll(m));
-}
-
-// the float64 epilogue of one 128 x 128 tile from the lane's 32 packed mismatch counters (k_mh_compare_p12's)
-__device__ __forceinline__ void r12_store_tile(const uint32_t (&mis)[8][4], uint32_t nn, const double *ratio_tab, double *__restrict__ out,
-                                               int64_t ld, int64_t I0, int64_t J0, int tx, int ty, int pace = 0) {
-  const char *tb = reinterpret_cast<const char *>(ratio_tab);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    double v0[8], v1[8];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint32_t m0 = nn - mis[2 * g][c], m1 = nn - mis[2 * g + 1][c];
-      v0[2 * c] = *reinterpret_cast<const double *>(tb + ((m0 << 3) & 0x7fff8u));
-      v0[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m0 >> 13) & 0x7fff8u));
-      v1[2 * c] = *reinterpret_cast<const double *>(tb + ((m1 << 3) & 0x7fff8u));
-      v1[2 * c + 1] = *reinterpret_cast<const double *>(tb + ((m1 >> 13) & 0x7fff8u));
-    }
-    double *orow = out + (I0 + 32 * g + 2 * ty) * ld + (J0 + 2 * tx);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      nt_store2(orow + 32 * q, v0[2 * q], v0[2 * q + 1]);
-      nt_store2(orow + ld + 32 * q, v1[2 * q], v1[2 * q + 1]);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c)                              // mirrored store (src/minHash.cpp:176)
-      nt_store2(out + (J0 + 32 * (c >> 1) + 2 * tx + (c & 1)) * ld + (I0 + 32 * g + 2 * ty), v0[c], v1[c]);
-    // pacing (store role): at most `pace` stores of this wave in flight before the next 16 are issued
-    if (pace == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (pace == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (pace == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (pace == 4) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-  }
-}
-
-__global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_r12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
-                                                                  double *__restrict__ out, int64_t ld, int64_t ntiles, int64_t per_xcd,
-                                                                  R12Ctl *__restrict__ ctl, u32x4_t *__restrict__ scratch, int occ, int max_mbox, int dbg) {
-  constexpr int PL = 12, SEGS = 3, STAGE_UNITS = 2 * K2_TILE * SEGS;
-  __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring (compute role)
-  __shared__ double ratio_tab[R12_TABLE];
-  __shared__ unsigned s_ctl[16];
-  const int T = (int)((n + K2_TILE - 1) / K2_TILE);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int xcd = blockIdx.x & 7;
-  for (int c = tid; c <= n_hash; c += K2_THREADS) ratio_tab[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
-  if (tid == 0) {
-    const unsigned key = r12_cu_key();
-    const unsigned t = atomicAdd(&ctl->cu_tickets[key], 1u);
-    unsigned mb = 0xffffffffu;
-    if ((int)t < occ - 1 && t < 4u) {                          // a compute workgroup of the CU's first wave of residents: gets a mailbox
-      mb = atomicAdd(&ctl->n_mbox, 1u);
-      if (mb < (unsigned)max_mbox) r12_st(&ctl->mbox_of[key][t], mb + 1u); else mb = 0xffffffffu;
-    }
-    s_ctl[0] = t; s_ctl[1] = key; s_ctl[2] = mb;
-  }
-  __syncthreads();
-  const unsigned ticket = __builtin_amdgcn_readfirstlane(s_ctl[0]), key = __builtin_amdgcn_readfirstlane(s_ctl[1]);
-  const unsigned my_mb = __builtin_amdgcn_readfirstlane(s_ctl[2]);
-  const uint32_t nn = (uint32_t)n_hash * 0x10001u;             // two match counts per register (no borrow: each <= n_hash)
-  const int tx0 = ((wave & 1) << 3) + (lane & 7), ty0 = ((wave >> 1) << 3) + (lane >> 3);
-
-  // ---- the consumer loop: take published tiles out of mailboxes (this CU's first, then anybody's) and store them as float64.
-  // A mailbox's `consumed` word is (tiles taken << 1) | locked: one consumer at a time owns a mailbox, for the time it takes to
-  // load a tile's counters.  Runs until every tile of the launch is stored -- store-role workgroups from the start, compute
-  // workgroups once the tile ids have run out (nobody idles in the tail, and a mailbox nobody polls is drained then).
-  auto consume_until_done = [&]() {
-    auto store_prio = [&]() {                                  // wave priority while a tile is being stored (experiments: dbg bits 8-9)
-      switch ((dbg >> 8) & 3) {
-        case 0: __builtin_amdgcn_s_setprio(1); break;
-        case 1: __builtin_amdgcn_s_setprio(2); break;
-        case 2: __builtin_amdgcn_s_setprio(3); break;
-        default: break;
-      }
-    };
-    const int nbox = occ - 1 < 3 ? occ - 1 : 3;
-    auto try_claim = [&](unsigned m) -> bool {                  // thread 0 only; fills s_ctl[5..7] and takes the lock
-      const unsigned cw = r12_ld(&ctl->consumed[m]);
-      if ((cw & 1u) || r12_ld(&ctl->published[m]) <= (cw >> 1)) return false;
-      if (atomicCAS(&ctl->consumed[m], cw, cw | 1u) != cw) return false;     // (somebody else took the mailbox)
-      s_ctl[5] = m; s_ctl[6] = cw >> 1; s_ctl[7] = r12_ld(&ctl->tile_of[m][(cw >> 1) % R12_RING]);
-      return true;
-    };
-    unsigned box[3] = {0u, 0u, 0u};                            // thread 0: mailbox id + 1 of this CU's compute workgroups, once seen
-    for (;;) {
-      r12_barrier();                                             // everybody has read the previous round's s_ctl words
-      if (tid == 0) {
-        unsigned found = 0u;
-        for (int j = 0; j < nbox && !found; ++j) {
-          if (!box[j]) box[j] = r12_ld(&ctl->mbox_of[key][j]);
-          if (box[j] && try_claim(box[j] - 1u)) found = 1u;
-        }
-        // the sweep over everybody's mailboxes is for the tail: only once this XCD's tile ids have run out
-        if (!found && !r12_ld(&ctl->exhausted[xcd][0])) { found = 3u; __builtin_amdgcn_s_sleep(64); }
-        s_ctl[4] = found;
-        s_ctl[11] = 0xffffffffu;
-        s_ctl[12] = r12_ld(&ctl->n_mbox);
-      }
-      r12_barrier();
-      unsigned found = __builtin_amdgcn_readfirstlane(s_ctl[4]);
-      if (found == 3u) continue;                                 // nothing at home yet: look again
-      if (!found) {                                              // the tail: every lane looks at a few mailboxes
-        const unsigned nm = min(__builtin_amdgcn_readfirstlane(s_ctl[12]), (unsigned)max_mbox);
-        for (unsigned m = (unsigned)tid; m < nm; m += K2_THREADS) {
-          const unsigned cw = r12_ld(&ctl->consumed[m]);
-          if (!(cw & 1u) && r12_ld(&ctl->published[m]) > (cw >> 1)) { atomicMin(&s_ctl[11], m); break; }
-        }
-        r12_barrier();
-        if (tid == 0) {
-          const unsigned cand = s_ctl[11];
-          unsigned f = 0u;
-          if (cand != 0xffffffffu) f = try_claim(cand) ? 1u : 0u;
-          else if (r12_ld(&ctl->tiles_done) >= r12_ld(&ctl->n_taken)) f = 2u;   // every tile is stored
-          else __builtin_amdgcn_s_sleep(32);
-          s_ctl[4] = f;
-        }
-        r12_barrier();
-        found = __builtin_amdgcn_readfirstlane(s_ctl[4]);
-        if (found == 2u) break;
-        if (!found) continue;
-      }
-      store_prio();
-      const unsigned mbf = __builtin_amdgcn_readfirstlane(s_ctl[5]), cnt = __builtin_amdgcn_readfirstlane(s_ctl[6]);
-      const int Lt = (int)__builtin_amdgcn_readfirstlane(s_ctl[7]);
-      const u32x4_t *src = scratch + ((size_t)mbf * R12_RING + (cnt % R12_RING)) * R12_TILE_UNITS + tid;
-      u32x4_t w0, w1, w2, w3, w4, w5, w6, w7;
-      asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
-                   "global_load_dwordx4 %1, %9, off sc1\n\t"
-                   "global_load_dwordx4 %2, %10, off sc1\n\t"
-                   "global_load_dwordx4 %3, %11, off sc1\n\t"
-                   "global_load_dwordx4 %4, %12, off sc1\n\t"
-                   "global_load_dwordx4 %5, %13, off sc1\n\t"
-                   "global_load_dwordx4 %6, %14, off sc1\n\t"
-                   "global_load_dwordx4 %7, %15, off sc1\n\t"
-                   "s_waitcnt vmcnt(0)"
-                   : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "=&v"(w7)
-                   : "v"(src), "v"(src + K2_THREADS), "v"(src + 2 * K2_THREADS), "v"(src + 3 * K2_THREADS), "v"(src + 4 * K2_THREADS),
-                     "v"(src + 5 * K2_THREADS), "v"(src + 6 * K2_THREADS), "v"(src + 7 * K2_THREADS)
-                   : "memory");
-      r12_barrier();                                             // every lane holds its counters: the slot may be written again
-      if (tid == 0) r12_st(&ctl->consumed[mbf], (cnt + 1u) << 1);   // count + unlock in one word
-      const uint32_t mis[8][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w},
-                                  {w4.x, w4.y, w4.z, w4.w}, {w5.x, w5.y, w5.z, w5.w}, {w6.x, w6.y, w6.z, w6.w}, {w7.x, w7.y, w7.z, w7.w}};
-      TileId tt;
-      tt.ti = (int)((unsigned)Lt >> 16); tt.tj = (int)((unsigned)Lt & 0xffffu); tt.valid = true;
-      if (dbg & 1024) { tt.ti = 0; tt.tj = 1 + (int)(blockIdx.x & 3); }   // (experiment: every tile lands on the same few -- L2-resident -- tiles)
-      if (!(dbg & 1)) r12_store_tile(mis, nn, ratio_tab, out, ld, (int64_t)tt.ti * K2_TILE, (int64_t)tt.tj * K2_TILE, tx0, ty0, (dbg >> 4) & 7);
-      if (tid == 0) atomicAdd(&ctl->tiles_done, 1u);
-      __builtin_amdgcn_s_setprio(0);                             // polling never competes with the plane loops
-    }
-  };
-
-  if (occ >= 2 && (int)(ticket % (unsigned)occ) == occ - 1) {   // ================= store role =================
-    if (dbg & 8) return;                                         // (experiment: no store role at all)
-    consume_until_done();
-    return;
-  }
-
-  // ================= compute role =================
-  const int lim = (int)(((int64_t)(xcd + 1) * per_xcd < ntiles) ? (int64_t)(xcd + 1) * per_xcd : ntiles);
-  const PlaneGeom pg = plane_geom(n, n_hash, PL);
-  const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)wave);
-  const uint64_t block_bytes = (uint64_t)pg.nst * (128u * PL * 4u);
-  const uint64_t wave_base = reinterpret_cast<uint64_t>(planes) + (wave_u >= 2 ? (uint64_t)pg.copy_words * 4u : 0u) + (wave_u & 1u) * 3072u;
-  auto source_of = [&](const TileId &t) -> uint64_t { return wave_base + (uint64_t)(wave_u >= 2 ? t.tj : t.ti) * block_bytes; };
-  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)lds_ab);
-  const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = 128u * PL * 4u;
-  register uint32_t r120 asm("v120") = lds_base + (uint32_t)(ty0 * SEGS * 16);
-  register uint32_t r121 asm("v121") = lds_base + (uint32_t)((K2_TILE * SEGS + tx0 * SEGS) * 16);
-  register uint32_t r124 asm("v124") = (uint32_t)tid * 4u;
-  TileId cur, nxt;
-  int fetch_no = 0;
-  auto next_dyn = [&](TileId &t) -> int {                     // next tile id of this XCD's range that the block takes
-    for (;;) {
-      if (tid == 0) s_ctl[8 + (fetch_no & 1)] = atomicAdd(&ctl->next[xcd][0], 1u);
-      r12_barrier();
-      const int Lq = (int)((int64_t)xcd * per_xcd) + (int)__builtin_amdgcn_readfirstlane(s_ctl[8 + (fetch_no & 1)]);
-      ++fetch_no;
-      if (Lq >= lim) {
-        if (Lq == lim && tid == 0) r12_st(&ctl->exhausted[xcd][0], 1u);   // the first draw past the end says so
-        return lim;
-      }
-      int To = T;
-      asm volatile("" : "+s"(To));
-      t = decode_tile(Lq, To, To, true);
-      t.ti = __builtin_amdgcn_readfirstlane(t.ti);
-      t.tj = __builtin_amdgcn_readfirstlane(t.tj);
-      if (t.valid && a12_takes(t.ti, t.tj, n, ld, out, true)) return Lq;
-    }
-  };
-  int L = next_dyn(cur);
-  uint32_t flags = 1u, phase = 0u;
-  unsigned np = 0u, nc_seen = 0u, pend = 0u;                    // tiles put into the mailbox / seen consumed; 1: the last one is not published yet
-  while (L < lim) {
-    const int Ln = next_dyn(nxt);
-    if (Ln < lim) flags |= 2u;
-    const uint64_t src = source_of(cur), src_n = source_of(nxt);
-    const uint32_t sl = __builtin_amdgcn_readfirstlane((uint32_t)src), sh = __builtin_amdgcn_readfirstlane((uint32_t)(src >> 32));
-    const uint32_t nl = __builtin_amdgcn_readfirstlane((uint32_t)src_n), nh = __builtin_amdgcn_readfirstlane((uint32_t)(src_n >> 32));
-    const uint32_t fl = __builtin_amdgcn_readfirstlane(flags), sp = __builtin_amdgcn_readfirstlane(phase * (uint32_t)(STAGE_UNITS * 16));
-    uint32_t mis[8][4];
-    uint32_t tid_after;
-    {
-#define K2_CNT(i) register uint32_t c##i asm("v" #i);
-      K2_CNT(64) K2_CNT(65) K2_CNT(66) K2_CNT(67) K2_CNT(68) K2_CNT(69) K2_CNT(70) K2_CNT(71) K2_CNT(72) K2_CNT(73) K2_CNT(74)
-      K2_CNT(75) K2_CNT(76) K2_CNT(77) K2_CNT(78) K2_CNT(79) K2_CNT(80) K2_CNT(81) K2_CNT(82) K2_CNT(83) K2_CNT(84) K2_CNT(85)
-      K2_CNT(86) K2_CNT(87) K2_CNT(88) K2_CNT(89) K2_CNT(90) K2_CNT(91) K2_CNT(92) K2_CNT(93) K2_CNT(94) K2_CNT(95)
-#undef K2_CNT
-      asm volatile(
-#include K2_LOOP_INC_P
-          : "=v"(c64), "=v"(c65), "=v"(c66), "=v"(c67), "=v"(c68), "=v"(c69), "=v"(c70), "=v"(c71), "=v"(c72), "=v"(c73), "=v"(c74),
-            "=v"(c75), "=v"(c76), "=v"(c77), "=v"(c78), "=v"(c79), "=v"(c80), "=v"(c81), "=v"(c82), "=v"(c83), "=v"(c84), "=v"(c85),
-            "=v"(c86), "=v"(c87), "=v"(c88), "=v"(c89), "=v"(c90), "=v"(c91), "=v"(c92), "=v"(c93), "=v"(c94), "=v"(c95)
-          : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh), [nl] "s"(nl),
-            [nh] "s"(nh), [fl] "s"(fl), [sp] "s"(sp), "v"(r120), "v"(r121), "v"(r124)
-          : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",
-            "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
-            "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
-            "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
-            "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",
-            "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
-            "v117", "v118", "v119", "v122", "v123");
-      asm volatile("" : "+v"(r124));
-      tid_after = r124 >> 2;
-      const uint32_t cnt[32] = {c64, c65, c66, c67, c68, c69, c70, c71, c72, c73, c74, c75, c76, c77, c78, c79,
-                                c80, c81, c82, c83, c84, c85, c86, c87, c88, c89, c90, c91, c92, c93, c94, c95};
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mis[r][c] = cnt[4 * r + c];
-    }
-    // the block's counted vmcnt waits and stage barriers (>= 3 stages) imply that EVERY wave's mailbox stores of the previous
-    // tile have completed: now it may be published
-    if (pend && tid_after == 0u) r12_st(&ctl->published[my_mb], np);
-    bool fast = my_mb != 0xffffffffu;
-    if (dbg & 4) {                                               // experiment: the compute role alone (nothing is stored)
-      if (tid_after == 0u) atomicAdd(&ctl->tiles_done, 1u);
-      cur = nxt; L = Ln; flags = 0u; phase = (phase + nstage) % 3u;
-      continue;
-    }
-    if (fast && np - nc_seen >= (unsigned)R12_RING) {            // the mailbox looked full last time: look again
-      if (tid_after == 0u) s_ctl[10] = r12_ld(&ctl->consumed[my_mb]);
-      r12_barrier();
-      nc_seen = __builtin_amdgcn_readfirstlane(s_ctl[10]) >> 1;   // (tiles taken << 1) | locked
-      fast = np - nc_seen < (unsigned)R12_RING;
-    }
-    if (fast) {
-      const unsigned slot = np % R12_RING;
-      u32x4_t *dst = scratch + ((size_t)my_mb * R12_RING + slot) * R12_TILE_UNITS + tid_after;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const u32x4_t v = {mis[q][0], mis[q][1], mis[q][2], mis[q][3]};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + q * K2_THREADS), "v"(v) : "memory");
-      }
-      if (tid_after == 0u) r12_st(&ctl->tile_of[my_mb][slot], ((unsigned)cur.ti << 16) | (unsigned)cur.tj);   // T < 2^16 (the launcher checks)
-      np += 1u;
-      pend = 1u;
-    } else {                                                     // mailbox full (or none): this workgroup stores the tile itself
-      const int wave_e = (int)tid_after >> 6, lane_e = (int)tid_after & 63;
-      const int tx = ((wave_e & 1) << 3) + (lane_e & 7), ty = ((wave_e >> 1) << 3) + (lane_e >> 3);
-      r12_store_tile(mis, nn, ratio_tab, out, ld, (int64_t)cur.ti * K2_TILE, (int64_t)cur.tj * K2_TILE, tx, ty);
-      if (tid_after == 0u) { atomicAdd(&ctl->tiles_done, 1u); atomicAdd(&ctl->slow_tiles, 1u); }
-      pend = 0u;
-    }
-    np = __builtin_amdgcn_readfirstlane(np);
-    pend = __builtin_amdgcn_readfirstlane(pend);
-    cur = nxt;
-    L = Ln;
-    flags = 0u;
-    phase = (phase + nstage) % 3u;
-  }
-  // the last tile: every wave waits for its own stores, then the count goes out
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (pend && threadIdx.x == 0) r12_st(&ctl->published[my_mb], np);
-  r12_barrier();
-  consume_until_done();                                          // out of tiles: help with the stores that are left
-}
-
-// ---- persistent 12-plane compare whose float64 stores ride INSIDE the next tile's stage loop (round 3) --------------------
-// The interleave rounds 1-2 asked for and had no registers for.  What unlocked it: three resident workgroups per CU run the
-// plane loop as fast as four (19.9 vs 20.1 ms without stores at N = 100k, profiles/r03_b_*), and at three per CU a wave may use
-// 168 VGPRs.  So the previous tile's 32 packed counters stay in v128..v159 while the block computes the next tile, and the block
-// (tools/gen_k2_asm.py K2ASM_INLOOP=1 -> k2_loop_p12q.inc) turns them into float64 stores a piece per stage: 16 pieces of four
-// 16-byte streaming stores = the 64 stores of a tile spread over the 16 stages (n_hash 481..512; 2 / 4 pieces per stage for 8 / 4
-// stages), issued from the wave that keeps computing -- no wave ever stands in front of a full store queue, and no tile's
-// stores arrive as a burst in the CU's in-order memory pipeline ahead of the LDS-DMA loads (what the store-role experiment of
-// this round showed to be the actual cost of K2's stores: tools/ubench/corun).  Tile ids come from a per-XCD counter
-// (the sliding L2 window of the one-tile-per-workgroup launch).  The last tile of a workgroup is stored by the C++ epilogue.
-#ifndef K2_LOOP_INC_Q
-#define K2_LOOP_INC_Q "k2_loop_p12q.inc"
+#ifdef DA_K2_EXPERIMENTS   // round 3's two float64-store experiments (k_mh_compare_r12 / _q12): built only by tools/experiments/build.sh, never into the product library
+#include "../../tools/experiments/k2_store_kernels.inc"
 #endif
-constexpr int Q12_TABLE = 520;               // doubles: n_hash <= 512 (16 stages at most: at least one piece per stage)
-__global__ __launch_bounds__(K2_THREADS, 3) void k_mh_compare_q12(const uint32_t *__restrict__ planes, int64_t n, int n_hash,
-                                                                  double *__restrict__ out, int64_t ld, int64_t ntiles, int64_t per_xcd,
-                                                                  R12Ctl *__restrict__ ctl) {
-  constexpr int PL = 12, SEGS = 3, STAGE_UNITS = 2 * K2_TILE * SEGS;
-  __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring
-  __shared__ double ratio_tab[Q12_TABLE];
-  __shared__ unsigned s_ctl[4];
-  const int T = (int)((n + K2_TILE - 1) / K2_TILE);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int xcd = blockIdx.x & 7;
-  for (int c = tid; c <= n_hash; c += K2_THREADS) ratio_tab[c] = (double)c / (double)n_hash;   // src/minHash.cpp:174
-  __syncthreads();
-  const int lim = (int)(((int64_t)(xcd + 1) * per_xcd < ntiles) ? (int64_t)(xcd + 1) * per_xcd : ntiles);
-  const PlaneGeom pg = plane_geom(n, n_hash, PL);
-  const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)wave);
-  const uint64_t block_bytes = (uint64_t)pg.nst * (128u * PL * 4u);
-  const uint64_t wave_base = reinterpret_cast<uint64_t>(planes) + (wave_u >= 2 ? (uint64_t)pg.copy_words * 4u : 0u) + (wave_u & 1u) * 3072u;
-  auto source_of = [&](const TileId &t) -> uint64_t { return wave_base + (uint64_t)(wave_u >= 2 ? t.tj : t.ti) * block_bytes; };
-  const int tx0 = ((wave & 1) << 3) + (lane & 7), ty0 = ((wave >> 1) << 3) + (lane >> 3);
-  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)lds_ab);
-  const uint32_t tab_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)ratio_tab);
-  const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = 128u * PL * 4u;
-  const uint32_t kk = 16u / nstage;                            // pieces per stage (the launcher checks 16 % nstage == 0)
-  const uint32_t nn = (uint32_t)n_hash * 0x10001u;
-  const uint32_t l8 = (uint32_t)(ld * 8);
-  register uint32_t r119 asm("v119") = (uint32_t)((2 * ty0) * ld + 2 * tx0) * 8u;   // the lane's byte offset inside a tile, direct rows
-  register uint32_t r120 asm("v120") = lds_base + (uint32_t)(ty0 * SEGS * 16);
-  register uint32_t r121 asm("v121") = lds_base + (uint32_t)((K2_TILE * SEGS + tx0 * SEGS) * 16);
-  register uint32_t r124 asm("v124") = (uint32_t)tid * 4u;
-  register uint32_t r127 asm("v127") = (uint32_t)((2 * tx0) * ld + 2 * ty0) * 8u;   // ... mirrored rows
-  TileId cur, nxt, prv;
-  prv.ti = prv.tj = 0; prv.valid = false;
-  int fetch_no = 0;
-  auto next_dyn = [&](TileId &t) -> int {
-    for (;;) {
-      if (tid == 0) s_ctl[fetch_no & 1] = atomicAdd(&ctl->next[xcd][0], 1u);
-      r12_barrier();
-      const int Lq = (int)((int64_t)xcd * per_xcd) + (int)__builtin_amdgcn_readfirstlane(s_ctl[fetch_no & 1]);
-      ++fetch_no;
-      if (Lq >= lim) return lim;
-      int To = T;
-      asm volatile("" : "+s"(To));
-      t = decode_tile(Lq, To, To, true);
-      t.ti = __builtin_amdgcn_readfirstlane(t.ti);
-      t.tj = __builtin_amdgcn_readfirstlane(t.tj);
-      if (t.valid && a12_takes(t.ti, t.tj, n, ld, out, true)) return Lq;
-    }
-  };
-#define K2_CNT(i) register uint32_t c##i asm("v" #i) = 0u;
-  K2_CNT(64) K2_CNT(65) K2_CNT(66) K2_CNT(67) K2_CNT(68) K2_CNT(69) K2_CNT(70) K2_CNT(71) K2_CNT(72) K2_CNT(73) K2_CNT(74)
-  K2_CNT(75) K2_CNT(76) K2_CNT(77) K2_CNT(78) K2_CNT(79) K2_CNT(80) K2_CNT(81) K2_CNT(82) K2_CNT(83) K2_CNT(84) K2_CNT(85)
-  K2_CNT(86) K2_CNT(87) K2_CNT(88) K2_CNT(89) K2_CNT(90) K2_CNT(91) K2_CNT(92) K2_CNT(93) K2_CNT(94) K2_CNT(95)
-#undef K2_CNT
-  int L = next_dyn(cur);
-  uint32_t flags = 1u, phase = 0u, pw = 0u;
-  while (L < lim) {
-    const int Ln = next_dyn(nxt);
-    if (Ln < lim) flags |= 2u;
-    const uint64_t src = source_of(cur), src_n = source_of(nxt);
-    const uint64_t od = reinterpret_cast<uint64_t>(out + ((int64_t)prv.ti * K2_TILE * ld + (int64_t)prv.tj * K2_TILE));
-    const uint64_t om = reinterpret_cast<uint64_t>(out + ((int64_t)prv.tj * K2_TILE * ld + (int64_t)prv.ti * K2_TILE));
-    const uint32_t sl = __builtin_amdgcn_readfirstlane((uint32_t)src), sh = __builtin_amdgcn_readfirstlane((uint32_t)(src >> 32));
-    const uint32_t nl = __builtin_amdgcn_readfirstlane((uint32_t)src_n), nh = __builtin_amdgcn_readfirstlane((uint32_t)(src_n >> 32));
-    const uint32_t odl = __builtin_amdgcn_readfirstlane((uint32_t)od), odh = __builtin_amdgcn_readfirstlane((uint32_t)(od >> 32));
-    const uint32_t oml = __builtin_amdgcn_readfirstlane((uint32_t)om), omh = __builtin_amdgcn_readfirstlane((uint32_t)(om >> 32));
-    const uint32_t fl = __builtin_amdgcn_readfirstlane(flags), sp = __builtin_amdgcn_readfirstlane(phase * (uint32_t)(STAGE_UNITS * 16));
-    const uint32_t pwu = __builtin_amdgcn_readfirstlane(pw);
-#ifdef K2Q_TIMING
-    uint32_t q_tw = 0, q_tbr = 0;
-    const unsigned long long q_t0 = __builtin_readcyclecounter();
-#endif
-    asm volatile(
-#include K2_LOOP_INC_Q
-        : "+v"(c64), "+v"(c65), "+v"(c66), "+v"(c67), "+v"(c68), "+v"(c69), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73), "+v"(c74),
-          "+v"(c75), "+v"(c76), "+v"(c77), "+v"(c78), "+v"(c79), "+v"(c80), "+v"(c81), "+v"(c82), "+v"(c83), "+v"(c84), "+v"(c85),
-          "+v"(c86), "+v"(c87), "+v"(c88), "+v"(c89), "+v"(c90), "+v"(c91), "+v"(c92), "+v"(c93), "+v"(c94), "+v"(c95)
-#ifdef K2Q_TIMING
-          , [tw] "=s"(q_tw), [tbr] "=s"(q_tbr)
-#endif
-        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh), [nl] "s"(nl),
-          [nh] "s"(nh), [fl] "s"(fl), [sp] "s"(sp), [tb] "s"(tab_base), [nn] "s"(nn), [odl] "s"(odl), [odh] "s"(odh), [oml] "s"(oml),
-          [omh] "s"(omh), [l8] "s"(l8), [pw] "s"(pwu), [kk] "s"(kk), "v"(r119), "v"(r120), "v"(r121), "v"(r124), "v"(r127)
-        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
-          "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v125", "v126",
-          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
-          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
-          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
-          "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",
-          "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
-          "v117", "v118", "v122", "v123",
-          "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143",
-          "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",
-          "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
-#ifdef K2Q_TIMING
-    if (threadIdx.x == 0) {                                      // (timing build) wave 0's cycles: DMA wait, barrier wait, whole block, blocks
-      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[0]), (unsigned long long)q_tw);
-      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[2]), (unsigned long long)q_tbr);
-      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[4]), __builtin_readcyclecounter() - q_t0);
-      atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->published[6]), 1ull);
-    }
-#endif
-    pw = (flags & 4u) ? 4u * kk : 0u;                            // stores per stage the block just issued
-    prv = cur;
-    cur = nxt;
-    L = Ln;
-    flags = 4u;                                                  // not the first tile any more; the next block stores this one
-    phase = (phase + nstage) % 3u;
-  }
-  // the workgroup's last tile: stored the ordinary way (the block's last stores may still be in flight: different addresses)
-  if (prv.valid || (flags & 4u)) {
-    asm volatile("" : "+v"(r124));
-    const uint32_t tid_after = r124 >> 2;
-    const uint32_t cnt[32] = {c64, c65, c66, c67, c68, c69, c70, c71, c72, c73, c74, c75, c76, c77, c78, c79,
-                              c80, c81, c82, c83, c84, c85, c86, c87, c88, c89, c90, c91, c92, c93, c94, c95};
-    uint32_t mis[8][4];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) mis[r][c] = cnt[4 * r + c];
-    const int wave_e = (int)tid_after >> 6, lane_e = (int)tid_after & 63;
-    const int tx = ((wave_e & 1) << 3) + (lane_e & 7), ty = ((wave_e >> 1) << 3) + (lane_e >> 3);
-    r12_store_tile(mis, nn, ratio_tab, out, ld, (int64_t)prv.ti * K2_TILE, (int64_t)prv.tj * K2_TILE, tx, ty);
-  }
-}
 
 // PL = bit planes per group of 32 hash functions: 32 (raw uint32 values) or 16 / 12 / 8 (dictionary
 // codes of dict_kernels.hip, as many planes as the largest column dictionary needs: same equalities
@@ -1844,142 +1377,9 @@ int launch_minhash_signatures(const uint8_t *d_res, const int64_t *d_off, int64_
   return DA_OK;
 }
 
-// ---- scratch of the role-split kernel: control block + mailboxes, a few instances per device -----------------------------
-// An instance is in use from its launch until the event recorded behind it completes; launches that find every instance busy
-// (several streams / host threads comparing on one device at once) take the one-tile-per-workgroup kernel instead.
-namespace {
-struct R12Inst { R12Ctl *ctl = nullptr; u32x4_t *scratch = nullptr; hipEvent_t ev = nullptr; int max_mbox = 0; };
-struct R12Pool {
-  std::mutex m;
-  std::vector<R12Inst> inst[64];
-  R12Ctl *last_ctl[64] = {};
-};
-R12Pool &r12_pool() { static R12Pool *p = new R12Pool; return *p; }   // never destroyed: the HIP runtime may be gone at exit
-}  // namespace
-
-size_t release_compare_scratch() {
-  R12Pool &P = r12_pool();
-  std::lock_guard<std::mutex> g(P.m);
-  size_t freed = 0;
-  int cur = 0;
-  (void)hipGetDevice(&cur);
-  for (int d = 0; d < 64; ++d) {
-    auto &v = P.inst[d];
-    if (v.empty()) continue;
-    (void)hipSetDevice(d);
-    for (size_t i = 0; i < v.size();)
-      if (hipEventQuery(v[i].ev) == hipSuccess) {
-        freed += sizeof(R12Ctl) + (size_t)v[i].max_mbox * R12_RING * R12_TILE_UNITS * 16;
-        (void)hipFree(v[i].ctl); if (v[i].scratch) (void)hipFree(v[i].scratch); (void)hipEventDestroy(v[i].ev);
-        if (P.last_ctl[d] == v[i].ctl) P.last_ctl[d] = nullptr;
-        v.erase(v.begin() + (long)i);
-      } else ++i;
-  }
-  (void)hipSetDevice(cur);
-  return freed;
-}
-
-// diagnostics (tools/, tests): counters of the device's last role-split launch -- {tiles taken, tiles stored, tiles a compute
-// workgroup stored itself, mailboxes}; synchronises the device
-extern "C" int da_debug_k2_roles_stats(unsigned *out4) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DA_ERR_HIP;
-  R12Ctl *ctl;
-  { std::lock_guard<std::mutex> g(r12_pool().m); ctl = r12_pool().last_ctl[dev]; }
-  if (!ctl) { out4[0] = out4[1] = out4[2] = out4[3] = 0; return DA_OK; }
-  if (hipDeviceSynchronize() != hipSuccess) return DA_ERR_HIP;
-  unsigned h[4];
-  if (hipMemcpy(h, &ctl->n_taken, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return DA_ERR_HIP;
-  out4[0] = h[0]; out4[1] = h[1]; out4[2] = h[3]; out4[3] = h[2];
-  return DA_OK;
-}
-
-// a free scratch instance of the current device (nullptr: all busy / no memory); the caller holds the pool's mutex
-static R12Inst *r12_acquire(R12Pool &P, int dev, bool need_scratch, int cus) {
-  auto &v = P.inst[dev];
-  R12Inst *inst = nullptr;
-  for (auto &i : v)
-    if (hipEventQuery(i.ev) == hipSuccess) { inst = &i; break; }
-  (void)hipGetLastError();                                     // hipErrorNotReady of a busy instance is not an error
-  if (!inst) {
-    if (v.size() >= 3) return nullptr;
-    R12Inst ni;
-    if (hipMalloc(reinterpret_cast<void **>(&ni.ctl), sizeof(R12Ctl)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipEventCreateWithFlags(&ni.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ni.ctl); return nullptr; }
-    v.push_back(ni);
-    inst = &v.back();
-  }
-  if (need_scratch && !inst->scratch) {
-    const int max_mbox = std::min(R12_MAX_MBOX, cus * 4);
-    if (hipMalloc(reinterpret_cast<void **>(&inst->scratch), (size_t)max_mbox * R12_RING * R12_TILE_UNITS * 16) != hipSuccess) {
-      (void)hipGetLastError(); inst->scratch = nullptr; return nullptr;
-    }
-    inst->max_mbox = max_mbox;
-  }
-  return inst;
-}
-
-#ifdef K2Q_TIMING
-extern "C" int da_debug_k2_inloop_timing(unsigned long long *out4) {   // (timing build) sums over all blocks of the device's last q12 launch
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DA_ERR_HIP;
-  R12Ctl *ctl;
-  { std::lock_guard<std::mutex> g(r12_pool().m); ctl = r12_pool().last_ctl[dev]; }
-  if (!ctl || hipDeviceSynchronize() != hipSuccess) return DA_ERR_HIP;
-  return hipMemcpy(out4, &ctl->published[0], 32, hipMemcpyDeviceToHost) == hipSuccess ? DA_OK : DA_ERR_HIP;
-}
+#ifdef DA_K2_EXPERIMENTS
+#include "../../tools/experiments/k2_store_host.inc"
 #endif
-
-// launches the role-split kernel (experiment, DYNAALIGN_K2_ROLES=1) or the in-loop-store kernel for the interior tiles of a symmetric
-// 12-plane float64 compare; *launched = false when it does not apply here (no free scratch instance, occupancy, ...) and the caller
-// should take k_mh_compare_a12
-static int launch_persistent_f64(bool roles, const uint32_t *d_planes, int64_t n, int n_hash, double *d_out, int64_t ld, int64_t ntiles,
-                                 int64_t per_xcd, int T, hipStream_t stream, bool *launched) {
-  *launched = false;
-  int dev = 0;
-  DA_HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return DA_OK;
-  static std::atomic<int> occ_c[2], cus_c;
-  const int ki = roles ? 0 : 1;
-  if (!occ_c[ki].load()) {
-    int occ = 0;
-    if (roles) DA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mh_compare_r12, K2_THREADS, 0));
-    else DA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mh_compare_q12, K2_THREADS, 0));
-    hipDeviceProp_t prop;
-    DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    cus_c.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-    occ_c[ki].store(occ > 0 ? occ : 1);
-    if (getenv("DYNAALIGN_TRACE")) fprintf(stderr, "[dynaalign] %s: %d resident workgroups per CU, %d CUs\n", roles ? "k_mh_compare_r12" : "k_mh_compare_q12", occ, cus_c.load());
-  }
-  int occ = occ_c[ki].load();
-  if (const char *e = getenv("DYNAALIGN_K2_WG_PER_CU")) occ = std::max(1, std::min(occ, atoi(e)));
-  const int cus = cus_c.load();
-  if (roles && occ < 2) return DA_OK;
-  R12Pool &P = r12_pool();
-  std::lock_guard<std::mutex> g(P.m);
-  R12Inst *inst = r12_acquire(P, dev, roles, cus);
-  if (!inst) return DA_OK;
-  const int wg_per_xcd = occ * ((cus + 7) / 8);
-  if (roles) {
-    DA_HIP_TRY(hipMemsetAsync(inst->ctl, 0, sizeof(R12Ctl), stream));
-    hipLaunchKernelGGL(k_r12_setup, dim3((unsigned)ceil_div(ntiles, 256)), dim3(256), 0, stream, inst->ctl, n, ld, static_cast<const void *>(d_out), ntiles, T);
-    hipLaunchKernelGGL(k_mh_compare_r12, dim3((unsigned)(8 * wg_per_xcd)), dim3(K2_THREADS), 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd,
-                       inst->ctl, inst->scratch, occ, inst->max_mbox, getenv("DYNAALIGN_K2_ROLES_DEBUG") ? atoi(getenv("DYNAALIGN_K2_ROLES_DEBUG")) : 0);
-  } else {
-#ifdef K2Q_TIMING
-    DA_HIP_TRY(hipMemsetAsync(inst->ctl, 0, sizeof(R12Ctl), stream));
-#else
-    DA_HIP_TRY(hipMemsetAsync(inst->ctl->next, 0, sizeof(inst->ctl->next), stream));      // the per-XCD tile counters are all it uses
-#endif
-    hipLaunchKernelGGL(k_mh_compare_q12, dim3((unsigned)(8 * wg_per_xcd)), dim3(K2_THREADS), 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd,
-                       inst->ctl);
-  }
-  DA_HIP_TRY(hipGetLastError());
-  DA_HIP_TRY(hipEventRecord(inst->ev, stream));
-  P.last_ctl[dev] = inst->ctl;
-  *launched = true;
-  return DA_OK;
-}
 
 int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                       int64_t row_begin, int64_t row_end, bool symmetric, int kind,
@@ -2056,12 +1456,9 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
     else
       hipLaunchKernelGGL(k_mh_compare_p12<false>, pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd, (int64_t)0);
   } else if (a12) {
-    // float64, OPT-IN experiments of round 3 (both bit-exact and tested; neither beats one tile per workgroup on MI355X):
-    // DYNAALIGN_K2_INLOOP=1: the persistent kernel whose stores ride inside the next tile's stage loop (k_mh_compare_q12; 16 / 8 / 4
-    // stages: a whole number of store pieces per stage) -- 25.2-25.4 vs 24.8-25.1 ms at N = 100k (22.6 with the store instructions
-    // removed, 19.9 without the store pieces: the pieces' instructions and the stores each cost the loop ~2.8 ms);
-    // DYNAALIGN_K2_ROLES=1: three compute workgroups + one storing workgroup per CU (k_mh_compare_r12) -- 25.9-26.3 ms
     bool roles = false;
+#ifdef DA_K2_EXPERIMENTS
+    // (experiment library only, tools/experiments/: DYNAALIGN_K2_INLOOP=1 -> k_mh_compare_q12, DYNAALIGN_K2_ROLES=1 -> k_mh_compare_r12)
     const int nst12 = (n_hash + K2_GROUP - 1) / K2_GROUP;
     if (kind == DA_OUT_F64 && ntiles < 0x7fffffffLL && T < 65536) {
       int rc_r = DA_OK;
@@ -2071,6 +1468,7 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
         rc_r = launch_persistent_f64(false, d_planes, n, n_hash, static_cast<double *>(d_out), ld, ntiles, per_xcd, T, stream, &roles);
       if (rc_r != DA_OK) return rc_r;
     }
+#endif
     if (roles) {
     } else if (kind == DA_OUT_F64)
       hipLaunchKernelGGL(k_mh_compare_a12<true>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);

@@ -243,10 +243,7 @@ def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash, bits)
     assert p12.bits == bits          # 16: k_mh_compare_a16 on the padded twin of the operand (8 steps per stage, ring of two stages); 14: its seven-step form
     want = _counts(sig_h) if n <= 3100 else None
     got = {}
-    # round 3's opt-in float64 kernels ride along: in-loop stores (k_mh_compare_q12: 4 / 8 / 16 stages, else it falls back by itself) and the
-    # role-split kernel (k_mh_compare_r12: 3 compute workgroups + 1 storing workgroup per CU; > 2 stages, n_hash < 504)
-    for tag, env in (("persistent", "DYNAALIGN_K2_PERSIST"), ("inloop", "DYNAALIGN_K2_INLOOP"), ("roles", "DYNAALIGN_K2_ROLES"), ("one_tile", None),
-                     ("compiled", "DYNAALIGN_K2_NO_ASM")):
+    for tag, env in (("persistent", "DYNAALIGN_K2_PERSIST"), ("one_tile", None), ("compiled", "DYNAALIGN_K2_NO_ASM")):
         if env:
             os.environ[env] = "1"
         try:
@@ -255,7 +252,7 @@ def test_hand_scheduled_and_compiled_12_plane_kernels_agree(da, n, n_hash, bits)
         finally:
             if env:
                 os.environ.pop(env, None)
-    for tag in ("persistent", "inloop", "roles", "one_tile"):
+    for tag in ("persistent", "one_tile"):
         assert np.array_equal(got[tag][0], got["compiled"][0]), tag
         assert np.array_equal(got[tag][1].view(np.uint64), got["compiled"][1].view(np.uint64)), tag
     if want is not None:

@@ -82,7 +82,7 @@ def test_committed_14_15_bit_includes_are_the_generators_output(tmp_path, bits):
 
 @pytest.mark.parametrize("ntiles,ns,tx,ty", [(1, 16, 0, 0), (3, 16, 5, 11), (4, 8, 15, 15), (3, 4, 7, 8), (2, 16, 9, 3)])
 def test_inloop_store_block_over_a_tile_sequence(ntiles, ns, tx, ty):
-    """the block of k_mh_compare_q12 (round 3): counters as before; the PREVIOUS tile's 64 float64 stores issued from inside the stage
+    """the block of k_mh_compare_q12 (round 3; an experiment kept under tools/experiments/, not in the product library): counters as before; the PREVIOUS tile's 64 float64 stores issued from inside the stage
     loop carry the right addresses and values (direct + mirrored, 16 / ns pieces per stage); and the counted vmcnt waits hold in
     an in-order model of loads and stores (a stage is never read before its three DMA pieces have retired)"""
     import sim_k2_asm
@@ -96,4 +96,4 @@ def test_committed_inloop_include_is_the_generators_output(tmp_path):
     env["K2ASM_INLOOP"] = "1"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env,
                           stdout=subprocess.DEVNULL)
-    assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p12q.inc")).read()
+    assert out.read_text() == open(os.path.join(ROOT, "tools", "experiments", "k2_loop_p12q.inc")).read()

@@ -42,7 +42,7 @@ def run15(tx=5, ty=11, seed=1, ns=16):
     return run_persistent(tx, ty, seed, ntiles=1, ns=ns, inc=INC_15, planes=15, slot_bytes=80, ring=2)
 
 
-INC_Q = os.path.join(os.path.dirname(INC), "k2_loop_p12q.inc")
+INC_Q = os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments", "k2_loop_p12q.inc")   # (experiment, not in the product build)
 
 
 def run_inloop(tx=5, ty=11, seed=1, ntiles=3, ns=16, n_hash=None):

@@ -69,6 +69,36 @@ KERNEL3(k_sadu8, A_SADU8) KERNEL3(k_med3, A_MED3) KERNEL3(k_cmp_vcc_addc, A_CMP_
 KERNEL3(k_cmp_sgpr, A_CMP_SGPR) KERNEL3(k_cndmask, A_CNDMASK) KERNEL3(k_addc, A_ADDC) KERNEL3(k_addco, A_ADDCO)
 KERNEL3(k_mbcnt, A_MBCNT) KERNEL3(k_dot4, A_DOT4) KERNEL3(k_dot2, A_DOT2) KERNEL3(k_subb, A_SUBB) KERNEL3(k_ffbh, A_FFBH)
 
+#define A_MAXF(d) "v_max_f32 " S(d) ", " S(d) ", %8\n\t"
+#define A_MINF(d) "v_min_f32 " S(d) ", " S(d) ", %8\n\t"
+#define A_MAX3F(d) "v_max3_f32 " S(d) ", " S(d) ", %8, %9\n\t"
+#define A_MED3F(d) "v_med3_f32 " S(d) ", " S(d) ", %8, %9\n\t"
+#define A_MAXIMUM3F(d) "v_maximum3_f32 " S(d) ", " S(d) ", %8, %9\n\t"
+#define A_ADDF(d) "v_add_f32 " S(d) ", " S(d) ", %8\n\t"
+#define A_FMAF(d) "v_fma_f32 " S(d) ", " S(d) ", %8, %9\n\t"
+#define A_OR(d) "v_or_b32 " S(d) ", " S(d) ", %8\n\t"
+#define A_LSHL(d) "v_lshlrev_b32 " S(d) ", 3, " S(d) "\n\t"
+#define A_ASHR(d) "v_ashrrev_i32 " S(d) ", 3, " S(d) "\n\t"
+#define A_MOV(d) "v_mov_b32 " S(d) ", %8\n\t"
+#define A_MAXU(d) "v_max_u32 " S(d) ", " S(d) ", %8\n\t"
+#define A_MAXI16(d) "v_max_i16 " S(d) ", " S(d) ", %8\n\t"
+#define A_MAXU16(d) "v_max_u16 " S(d) ", " S(d) ", %8\n\t"
+#define A_MAXF16(d) "v_max_f16 " S(d) ", " S(d) ", %8\n\t"
+#define A_PKMAXF16(d) "v_pk_max_f16 " S(d) ", " S(d) ", %8\n\t"
+#define A_ANDOR(d) "v_and_or_b32 " S(d) ", " S(d) ", %8, %9\n\t"
+#define A_ADD_SGPR(d) "v_add_u32 " S(d) ", s20, " S(d) "\n\t"
+#define A_ADD_LIT(d) "v_add_u32 " S(d) ", 0x12345, " S(d) "\n\t"
+#define A_ADD_INL(d) "v_add_u32 " S(d) ", 17, " S(d) "\n\t"
+#define A_MAXF_SGPR(d) "v_max_f32 " S(d) ", s20, " S(d) "\n\t"
+#define A_CNDMASK_VCC(d) "v_cndmask_b32_e32 " S(d) ", " S(d) ", %8, vcc\n\t"
+#define A_ADDMAXF(d) "v_add_u32 " S(d) ", " S(d) ", %8\n\tv_max_f32 " S(d) ", " S(d) ", %9\n\t"
+#define A_BITOP3_PAR(d) "v_bitop3_b32 " S(d) ", " S(d) ", %8, %8 bitop3:0xbe\n\t"
+KERNEL3(k_maxf, A_MAXF) KERNEL3(k_minf, A_MINF) KERNEL3(k_max3f, A_MAX3F) KERNEL3(k_med3f, A_MED3F) KERNEL3(k_maximum3f, A_MAXIMUM3F)
+KERNEL3(k_addf, A_ADDF) KERNEL3(k_fmaf, A_FMAF) KERNEL3(k_or, A_OR) KERNEL3(k_lshl, A_LSHL) KERNEL3(k_ashr, A_ASHR) KERNEL3(k_mov, A_MOV)
+KERNEL3(k_maxu, A_MAXU) KERNEL3(k_maxi16, A_MAXI16) KERNEL3(k_maxu16, A_MAXU16) KERNEL3(k_maxf16, A_MAXF16) KERNEL3(k_pkmaxf16, A_PKMAXF16)
+KERNEL3(k_andor, A_ANDOR) KERNEL3(k_add_sgpr, A_ADD_SGPR) KERNEL3(k_add_lit, A_ADD_LIT) KERNEL3(k_add_inl, A_ADD_INL) KERNEL3(k_maxf_sgpr, A_MAXF_SGPR)
+KERNEL3(k_cndmask_vcc, A_CNDMASK_VCC) KERNEL3(k_addmaxf, A_ADDMAXF)
+
 typedef void (*kern_t)(unsigned *, int, unsigned);
 double run(kern_t kern, int blocks, int iters, unsigned *out) {
   hipEvent_t e0, e1;
@@ -100,6 +130,13 @@ int main() {
       {"v_cndmask_b32 (sgpr sel)", k_cndmask, 1}, {"v_addc_co_u32 (sgpr in/out)", k_addc, 1},
       {"v_add_co_u32 (sgpr out)", k_addco, 1}, {"v_subb_co_u32", k_subb, 1},
       {"v_cmp_e32 vcc + v_addc_e32 (pair)", k_cmp_vcc_addc, 2},
+      {"v_max_f32", k_maxf, 1}, {"v_min_f32", k_minf, 1}, {"v_max3_f32", k_max3f, 1}, {"v_med3_f32", k_med3f, 1},
+      {"v_maximum3_f32", k_maximum3f, 1}, {"v_add_f32", k_addf, 1}, {"v_fma_f32", k_fmaf, 1}, {"v_or_b32", k_or, 1},
+      {"v_lshlrev_b32", k_lshl, 1}, {"v_ashrrev_i32", k_ashr, 1}, {"v_mov_b32", k_mov, 1}, {"v_max_u32", k_maxu, 1},
+      {"v_max_i16", k_maxi16, 1}, {"v_max_u16", k_maxu16, 1}, {"v_max_f16", k_maxf16, 1}, {"v_pk_max_f16", k_pkmaxf16, 1},
+      {"v_and_or_b32", k_andor, 1}, {"v_add_u32 (sgpr src0)", k_add_sgpr, 1}, {"v_add_u32 (literal)", k_add_lit, 1},
+      {"v_add_u32 (inline const)", k_add_inl, 1}, {"v_max_f32 (sgpr src0)", k_maxf_sgpr, 1}, {"v_cndmask_b32_e32 vcc", k_cndmask_vcc, 1},
+      {"v_add_u32 + v_max_f32 (dependent pair)", k_addmaxf, 2},
   };
   double base = 0;
   printf("%-36s %12s %10s\n", "instruction", "Ginst*64/s", "cost(v_add=1)");
