@@ -173,9 +173,13 @@ __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMA
   }
 }
 
-// (experiment switch: the row-ahead residue fetch helped the direct sweep, 466 -> 418 ms, and cost the ordered mode 98 -> 102 ms)
-template <bool ORD> constexpr bool getenv_free_prefetch_off() { return ORD; }
-template <int NMAX, bool CK, bool ORD>
+// Hand-scheduled rows (round 4; tools/gen_nw_asm.py -> nw_rows_p<NMAX>.inc): all DP rows of one sequence1 as ONE asm statement -- two rows
+// per sweep skewed by a column (no copy of the diagonal neighbour), every per-cell operand a VGPR, table reads issued a ring ahead with
+// counted waits.  ASM = true instances exist for the NMAX listed here; the compiled row below serves the rest and the int32 cell.
+#include "nw_rows_p12_bind.inc"
+#include "nw_rows_p20_bind.inc"
+template <int NMAX> constexpr bool nw_has_asm_rows() { return NMAX == 12 || NMAX == 20; }
+template <int NMAX, bool CK, bool ORD, bool ASM = false>
 __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short(   // <= 24 residues: keep 4 waves per SIMD (128 VGPRs)
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
@@ -319,11 +323,45 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
       // row 0 (reference :222-235) in combined form: only its max(M,Ix,Iy) feeds row 1's diagonal.
       // Iy[0][c+1] = -go - c*ge, in the moving frame (+ (c+1)*ge) the constant ge - go; no diagonal moves yet
       int32_t VM[NMAX], XP[NMAX];
+      if constexpr (!ASM) {                             // (the generated block initialises its own rows; with m == 0 VM is never read)
 #pragma unroll
-      for (int c = 0; c < NMAX; ++c) {
-        VM[c] = (ge - go) << CK_S2;
-        XP[c] = 0;                                      // Ix[0][.] = -inf is handled by FIRST
+        for (int c = 0; c < NMAX; ++c) {
+          VM[c] = (ge - go) << CK_S2;
+          XP[c] = 0;                                    // Ix[0][.] = -inf is handled by FIRST
+        }
       }
+      typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
+      if constexpr (ASM) {
+        static_assert(nw_has_asm_rows<NMAX>(), "no generated row block for this NMAX");
+        if (m > 0) {
+          // wave-uniform operands in SGPRs; the block moves the per-cell constants into VGPRs itself (an SGPR source halves the rate of
+          // v_add / v_bitop3, profiles/r04_a_ubench_inst_rate.txt)
+          const uint32_t m_s = __builtin_amdgcn_readfirstlane((uint32_t)m);
+          const uint32_t rc_s = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t *)&rowcodes[lr][0]);
+          const uint32_t tb_s = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t *)reinterpret_cast<const uint8_t *>(tabk));
+          const int32_t kx_s = ((ge - goe) << CK_S2) + (1 << CK_S), ky_s = (ge - goe) << CK_S2, pm_s = (1 << CK_S) - 1, pc_s = ~CK_PRI;
+          const int32_t vi_s = (ge - go) << CK_S2, l0_s = CK_NEG << CK_S2, xf_s = ((CK_NEG - min(goe, ge)) << CK_S2) + (1 << CK_S);
+          if constexpr (NMAX == 12) {
+            NW_ASM_DECL_12
+            asm volatile(
+#include "nw_rows_p12.inc"
+                : NW_ASM_OUTS_12
+                : [m] "s"(m_s), [rc] "s"(rc_s), [tb] "s"(tb_s), [kx] "s"(kx_s), [ky] "s"(ky_s), [pm] "s"(pm_s), [pc] "s"(pc_s),
+                  [vi] "s"(vi_s), [l0] "s"(l0_s), [xf] "s"(xf_s), NW_ASM_INS_12
+                : NW_ASM_CLOBBERS_12);
+            NW_ASM_COPY_12
+          } else {
+            NW_ASM_DECL_20
+            asm volatile(
+#include "nw_rows_p20.inc"
+                : NW_ASM_OUTS_20
+                : [m] "s"(m_s), [rc] "s"(rc_s), [tb] "s"(tb_s), [kx] "s"(kx_s), [ky] "s"(ky_s), [pm] "s"(pm_s), [pc] "s"(pc_s),
+                  [vi] "s"(vi_s), [l0] "s"(l0_s), [xf] "s"(xf_s), NW_ASM_INS_20
+                : NW_ASM_CLOBBERS_20);
+            NW_ASM_COPY_20
+          }
+        }
+      } else {
       // wave-uniform constants are parked in VGPRs: an SGPR source halves v_bitop3's issue rate
       auto in_vgpr = [](int32_t x) { int32_t v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; };
       const int32_t kx = in_vgpr(((ge - goe) << CK_S2) + (1 << CK_S));   // open a gap from M': -goe, +ge of the frame, priority 1
@@ -331,23 +369,25 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
       const int32_t pay_mask = in_vgpr((1 << CK_S) - 1), pri_clear = in_vgpr(~CK_PRI);
       // Ix[1][c] = max(NEG-goe, NEG-ge), priority 1, payload of row 0 (nothing)
       const int32_t ixf_first = ((CK_NEG - min(goe, ge)) << CK_S2) + (1 << CK_S);
-      // sequence1's residue of the NEXT row is fetched while this row's chain runs (round 3): the row loop used to open with
-      // ds_read_u8 + s_waitcnt lgkmcnt(0) + v_mad before it could issue its 20 table reads -- an LDS round trip per row in
-      // front of everything (and hipcc rotates a plain C++ prefetch back to that shape).  So the read is inline asm, issued a
-      // row ahead; LDS operations return in order and the extra outstanding one only makes the compiler's counted lgkmcnt waits
-      // stricter, never weaker.  The value is wave-uniform: in an SGPR the table-row offset is scalar arithmetic.
-      typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
+      // DIRECT sweep: sequence1's residue of the NEXT row is fetched while this row's chain runs (round 3: 466 -> 417 ms; the row loop
+      // otherwise opens with ds_read_u8 + s_waitcnt lgkmcnt(0) + v_mad in front of its 20 table reads, and hipcc rotates a plain C++
+      // prefetch back to that shape).  The value is in flight ACROSS two asm statements (read in one, wait in the next), so it lives in
+      // a FIXED register that nothing else in the kernel names (with an ordinary "=v" variable a compiler-inserted copy or
+      // spill between the two statements would capture a stale value; tests/test_nw_asm_model.py checks the disassembly: v127 appears
+      // only in these statements).  LDS operations return in order, so the extra outstanding read only makes the compiler's own
+      // counted lgkmcnt waits stricter.  The ordered mode does not use it (measured slower there; it runs the generated rows anyway).
+      constexpr bool PREFETCH = !ORD && NMAX <= 24;
       const uint32_t rc_addr = (uint32_t)(uintptr_t)(lds_u8_t *)&rowcodes[lr][0];
-      uint32_t code_v = 0u;
-      constexpr bool PREFETCH = !getenv_free_prefetch_off<ORD>();
+      register uint32_t code_v asm("v127");
       if (PREFETCH && m > 0) asm volatile("ds_read_u8 %0, %1" : "=v"(code_v) : "v"(rc_addr) : "memory");
       for (int32_t r = 1; r <= m; ++r) {
         // (making this offset opaque to the compiler turns the per-cell v_mad into a v_add but lets it
         // hoist all 20 lookups: 141 VGPRs / 3 waves per SIMD and 15 % slower -- measured, not kept)
         uint32_t row_off;
         if (PREFETCH) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(code_v) :: "memory");
-          row_off = __builtin_amdgcn_readfirstlane(code_v) * (24u * (uint32_t)sizeof(int32_t));
+          uint32_t code_s;
+          asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(code_s), "+v"(code_v) :: "memory");
+          row_off = code_s * (24u * (uint32_t)sizeof(int32_t));
           asm volatile("ds_read_u8 %0, %1" : "=v"(code_v) : "v"(rc_addr + (uint32_t)(r < m ? r : r - 1)) : "memory");
         } else {
           row_off = (uint32_t)rowcodes[lr][r - 1] * (24u * (uint32_t)sizeof(int32_t));
@@ -361,6 +401,7 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
           nw_row_ck<NMAX, true>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
         else
           nw_row_ck<NMAX, false>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
+      }
       }
       // ---- cell (m, nj): length = m + nj - D, score = score' - (m + nj)*ge
       mt = 0; ln = (uint32_t)m;                     // nj == 0: column-0 boundary
@@ -1229,8 +1270,18 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   dim3 grid((unsigned)ntiles), block(K3_THREADS);
 #define DA_K3_ARGS d_codes, d_off, n, st, (int32_t)gap_open, (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, \
                    d_score, ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast
+  // ordered mode (the duplicate route's DP), combined-key cell, a generated row block for this NMAX: the hand-scheduled rows (equal to
+  // the compiled row within 0.5 %, profiles/r04_c_nw_row_forms_in_kernel.txt; DYNAALIGN_NW_NO_ASM=1: the compiled row).  The direct sweep
+  // keeps the compiled row with its row-ahead residue read (2 % faster than the generated rows there).
+  const bool asm_rows = ck && !getenv("DYNAALIGN_NW_NO_ASM");
 #define DA_K3(NM)                                                                                                     \
   do {                                                                                                                \
+    if constexpr (nw_has_asm_rows<NM>()) {                                                                            \
+      if (asm_rows && ord_first) {                                                                                    \
+        hipLaunchKernelGGL((k_nw_short<NM, true, true, true>), grid, block, 0, stream, DA_K3_ARGS);                   \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
     if (ord_first) {                                                                                                  \
       if (ck) hipLaunchKernelGGL((k_nw_short<NM, true, true>), grid, block, 0, stream, DA_K3_ARGS);                   \
       else hipLaunchKernelGGL((k_nw_short<NM, false, true>), grid, block, 0, stream, DA_K3_ARGS);                     \
