@@ -28,6 +28,8 @@ SIGNATURES = {
     "da_abi_version": (_i32, []),
     "da_device_count": (_i32, []),
     "da_release_device_memory": (_sz, []),
+    "da_config_reload": (None, []),
+    "da_debug_comm_cache_state": (C.c_int, [C.c_int, C.c_void_p]),
     "da_hash_family_seeds": (_i32, [_u32, _i32, _vp]),
     "da_random_seed": (_u32, []),
     "da_similarity_mh": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
@@ -155,8 +157,31 @@ def load(path=None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    _lib = lib
-    return lib
+    _lib = _Library(lib)
+    return _lib
+
+
+def _switches():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("DYNAALIGN_")))
+
+
+class _Library:
+    """The loaded library.  The C side parses its DYNAALIGN_* switches once (da_common.hpp Config); tests, bench.py and the tools flip
+    switches inside one process, so this front end calls the library's reload hook whenever the process's DYNAALIGN_* environment
+    differs from what it was at the previous call -- the library itself never looks at the environment again."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "_seen", _switches())
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if name != "da_config_reload":
+            now = _switches()
+            if now != self._seen:
+                self._cdll.da_config_reload()
+                object.__setattr__(self, "_seen", now)
+        return fn
 
 
 def check(rc):

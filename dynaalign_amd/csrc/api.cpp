@@ -6,6 +6,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -68,8 +69,7 @@ struct BigCache {
     if ((size_t)dev >= budget.size()) budget.resize((size_t)dev + 1, 0);
     if (!budget[(size_t)dev]) {
       size_t total_b = 0;
-      int pct = 30;                                            // DYNAALIGN_BUFFER_CACHE_PCT: share of the device's memory that may stay parked
-      if (const char *e = getenv("DYNAALIGN_BUFFER_CACHE_PCT")) pct = std::max(0, std::min(90, atoi(e)));
+      const int pct = da::config().buffer_cache_pct;         // DYNAALIGN_BUFFER_CACHE_PCT: share of the device's memory that may stay parked (30)
       budget[(size_t)dev] = hipDeviceTotalMem(&total_b, dev) == hipSuccess && total_b ? total_b / 100 * (size_t)pct : (size_t)64 << 30;
       if (!budget[(size_t)dev]) budget[(size_t)dev] = 1;       // 0 % = park nothing (but do not ask again)
     }
@@ -128,7 +128,7 @@ struct DevBuf {
   int dev = 0;
   ~DevBuf() {
     if (!p) return;
-    if (cap >= BigCache::MIN_BYTES && !getenv("DYNAALIGN_NO_BUFFER_CACHE")) big_cache().park(dev, p, cap);
+    if (cap >= BigCache::MIN_BYTES && !da::config().no_buffer_cache) big_cache().park(dev, p, cap);
     else (void)hipFree(p);
   }
   int alloc(size_t bytes) {
@@ -277,7 +277,7 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes, const double *tabl
   constexpr size_t CHUNK = (size_t)64 << 20, SMALL = (size_t)8 << 20;   // SMALL: codes of n <= 2048 sequences
   constexpr int RING = 4, MAX_WORKERS = 32;
   int WORKERS = table ? 16 : 8;          // host threads per chunk (first-touch page faults of the destination parallelise)
-  if (const char *e = getenv("DYNAALIGN_D2H_THREADS")) WORKERS = std::max(1, std::min(MAX_WORKERS, atoi(e)));
+  if (da::config().d2h_threads > 0) WORKERS = std::min(MAX_WORKERS, da::config().d2h_threads);   // DYNAALIGN_D2H_THREADS
   {
     const unsigned hw = std::thread::hardware_concurrency();
     cpu_set_t cs;
@@ -296,7 +296,7 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes, const double *tabl
     widen_u16_to_f64(static_cast<double *>(dst), codes.data(), 0, bytes / 2, table);
     return DA_OK;
   }
-  if (getenv("DYNAALIGN_PLAIN_D2H") && !table) {
+  if (da::config().plain_d2h && !table) {
     DA_HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return DA_OK;
   }
@@ -348,7 +348,7 @@ int d2h_pipelined(void *dst, const void *d_src, size_t bytes, const double *tabl
 
 // DYNAALIGN_TRACE=1: wall-clock checkpoints of the host-pointer paths on stderr (where does T_h go?)
 struct Trace {
-  const bool on = getenv("DYNAALIGN_TRACE") != nullptr;
+  const bool on = da::config().trace;
   const char *what;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
   explicit Trace(const char *w) : what(w) {}
@@ -373,7 +373,7 @@ int64_t rows_per_block(int64_t n, size_t bytes_per_elem) {
     for (const auto &e : big_cache().parked) if (e.dev == dev) free_b += e.bytes;
   }
   size_t budget = free_b / 2;
-  if (const char *e = getenv("DYNAALIGN_BLOCK_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);
+  if (da::config().block_bytes) budget = (size_t)da::config().block_bytes;   // DYNAALIGN_BLOCK_BYTES
   int64_t rows = (int64_t)(budget / ((size_t)n * bytes_per_elem));
   rows = rows / 128 * 128;
   if (rows < 128) rows = 128;
@@ -384,6 +384,61 @@ int64_t rows_per_block(int64_t n, size_t bytes_per_elem) {
 }  // namespace da
 
 using namespace da;
+
+// ---- run-time switches: parsed once (da_common.hpp Config) -----------------------------------------------------------------------
+namespace da {
+namespace {
+bool env_flag(const char *name) { return getenv(name) != nullptr; }
+int64_t env_i64(const char *name, int64_t dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
+uint64_t env_u64(const char *name, uint64_t dflt) { const char *e = getenv(name); return e ? strtoull(e, nullptr, 10) : dflt; }
+Config parse_config() {
+  Config c;
+  c.mh_no_dedup = env_flag("DYNAALIGN_MH_NO_DEDUP");
+  c.mh_no_sparse = env_flag("DYNAALIGN_MH_NO_SPARSE");
+  c.mh_no_pipe = env_flag("DYNAALIGN_MH_NO_PIPE");
+  c.mh_pipe_one_stream = env_flag("DYNAALIGN_MH_PIPE_ONE_STREAM");
+  c.mh_dedup_min_n = env_i64("DYNAALIGN_MH_DEDUP_MIN_N", -1);
+  c.mh_dedup_max_pct = env_i64("DYNAALIGN_MH_DEDUP_MAX_PCT", -1);
+  c.mh_sparse_max_pairs = std::min<uint64_t>(env_u64("DYNAALIGN_MH_SPARSE_MAX_PAIRS", 400000000ull), 0xfffffff0ull);   // (32-bit entry offsets)
+  if (const char *e = getenv("DYNAALIGN_MH_EXPAND"))
+    c.mh_expand = !strcmp(e, "rows") ? 1 : !strcmp(e, "rowspipe") ? 2 : !strcmp(e, "pipe") ? 3 : !strcmp(e, "tiles") ? 4 : 0;
+  c.mh_pipe_step = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_MH_PIPE_STEP", 0));
+  c.mh_pipe_wg = (int)std::max<int64_t>(0, std::min<int64_t>(4, env_i64("DYNAALIGN_MH_PIPE_WG", 0)));
+  c.mh_pipe_head = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_MH_PIPE_HEAD", 0));
+  const int pb = (int)env_i64("DYNAALIGN_PLANE_BITS", 0);
+  c.plane_bits = (pb == 32 || pb == 16 || pb == 15 || pb == 14 || pb == 12) ? pb : 0;
+  c.k2_no_asm = env_flag("DYNAALIGN_K2_NO_ASM");
+  c.k2_persist = env_flag("DYNAALIGN_K2_PERSIST");
+  c.k2_wg_per_cu = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_K2_WG_PER_CU", 0));
+  c.nw_no_dedup = env_flag("DYNAALIGN_NW_NO_DEDUP");
+  c.nw_int32 = env_flag("DYNAALIGN_NW_INT32");
+  c.nw_no_asm = env_flag("DYNAALIGN_NW_NO_ASM");
+  c.nw_dedup_min_n = env_i64("DYNAALIGN_NW_DEDUP_MIN_N", -1);
+  c.no_host_widen = env_flag("DYNAALIGN_NO_HOST_WIDEN");
+  c.plain_d2h = env_flag("DYNAALIGN_PLAIN_D2H");
+  c.no_buffer_cache = env_flag("DYNAALIGN_NO_BUFFER_CACHE");
+  c.d2h_threads = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_D2H_THREADS", 0));
+  c.buffer_cache_pct = (int)std::max<int64_t>(0, std::min<int64_t>(90, env_i64("DYNAALIGN_BUFFER_CACHE_PCT", 30)));
+  c.block_bytes = env_u64("DYNAALIGN_BLOCK_BYTES", 0);
+  c.trace = env_flag("DYNAALIGN_TRACE");
+  c.louvain_debug = env_flag("DYNAALIGN_LOUVAIN_DEBUG");
+  c.louvain_threads = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_LOUVAIN_THREADS", 0));
+  return c;
+}
+std::atomic<const Config *> g_config{nullptr};
+}  // namespace
+const Config &config() {
+  const Config *c = g_config.load(std::memory_order_acquire);
+  if (!c) {
+    const Config *fresh = new Config(parse_config());
+    if (g_config.compare_exchange_strong(c, fresh, std::memory_order_acq_rel)) c = fresh;
+    else delete fresh;
+  }
+  return *c;
+}
+}  // namespace da
+// test hook: parse the environment again (the previous struct stays allocated: another host thread may still be reading it)
+extern "C" void da_config_reload(void) { da::g_config.store(new da::Config(da::parse_config()), std::memory_order_release); }
 
 extern "C" {
 
@@ -476,9 +531,7 @@ int da_dev_minhash_signatures(const uint8_t *d_residues, const int64_t *d_offset
 
 // signatures -> compare operand: dictionary codes (16 planes / group) when n allows, raw values otherwise
 static int env_plane_bits() {   // DYNAALIGN_PLANE_BITS: 32 = raw planes, 12 / 16 = at least that many code planes
-  const char *e = getenv("DYNAALIGN_PLANE_BITS");
-  const int v = e ? atoi(e) : 0;
-  return (v == 32 || v == 16 || v == 15 || v == 14 || v == 12) ? v : 0;
+  return da::config().plane_bits;
 }
 // The sparse route (minhash_kernels.hip "SPARSE route"): the caller of build_planes asks for it by passing a SparseHint; when the
 // dictionary says the signatures rarely agree (few matching incidences, no large class) build_planes returns with take = true and
@@ -499,7 +552,7 @@ static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_
     DA_HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, stream));
     DA_HIP_TRY(hipStreamSynchronize(stream));
     if (sparse && status[0] == 0 && status[1] >= 1 && status[1] <= 32768 && min_bits == 0 && n >= 2048 && n_hash + 1 <= 2048 &&
-        !getenv("DYNAALIGN_MH_NO_SPARSE")) {
+        !da::config().mh_no_sparse) {
       // how many (pair, hash function) incidences match, and how large is the largest class?  (one more read-back: ~0.15 ms)
       int64_t ld_ids = 0;
       const uint16_t *ids = mh_dictionary_codes(d_work, n, n_hash, &ld_ids);
@@ -623,8 +676,8 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   DA_HIP_TRY(hipEventRecord(ev[0], stream));
   const int64_t lds = sig_ld_for(n_hash);
   int64_t min_n = 2048;
-  if (const char *e = getenv("DYNAALIGN_MH_DEDUP_MIN_N")) min_n = atoll(e);   // tests lower it to reach the route with small inputs
-  const bool eligible = n >= min_n && n <= 0x7ffffff0LL && total > 0 && n_hash <= 2047 && !getenv("DYNAALIGN_MH_NO_DEDUP");
+  if (da::config().mh_dedup_min_n >= 0) min_n = da::config().mh_dedup_min_n;   // DYNAALIGN_MH_DEDUP_MIN_N: tests lower it to reach the route with small inputs
+  const bool eligible = n >= min_n && n <= 0x7ffffff0LL && total > 0 && n_hash <= 2047 && !da::config().mh_no_dedup;
   DevBuf plan_work;
   NwDedupPlan p{};
   int64_t U = n;
@@ -645,11 +698,11 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     // ... with the tile expansion.  With the row expansion (no gather, no copy of the table) the route costs ~1.5 + 26 f^2 + 14 ms one kernel after the
     // other: 24.4 ms at f = 0.60, 26.6 at f = 0.65 against 27 (12 code planes) - 30 ms (14) for the direct kernels (profiles/r03_q_dedup_threshold.txt): 0.68
     int64_t max_pct = expand_stream_ok(n, std::min<int64_t>(U, 65536), n_hash, d_out, ld) ? 68 : 60;
-    if (const char *e = getenv("DYNAALIGN_MH_DEDUP_MAX_PCT")) max_pct = atoll(e);
+    if (da::config().mh_dedup_max_pct >= 0) max_pct = da::config().mh_dedup_max_pct;   // DYNAALIGN_MH_DEDUP_MAX_PCT
     take = U > 0 && U * 100 <= n * max_pct && expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0) != 0;
     if (take && (rc = launch_nw_dedup_build(d_res, d_off, n, U, p, stream, true)) != DA_OK) return rc;   // ids by first occurrence
-    const char *form0 = getenv("DYNAALIGN_MH_EXPAND");
-    const bool rows_form = (!form0 || !strcmp(form0, "rows") || !strcmp(form0, "rowspipe")) && expand_stream_ok(n, U, n_hash, d_out, ld);
+    const int form0 = da::config().mh_expand;                      // DYNAALIGN_MH_EXPAND: 0 default, 1 rows, 2 rowspipe, 3 pipe, 4 tiles
+    const bool rows_form = form0 <= 2 && expand_stream_ok(n, U, n_hash, d_out, ld);
     if (take && !rows_form) {                                      // (the row expansion needs no schedule of output bands: one read-back less)
       // ub[b] = unique ids the input rows [0, 1024 b) use (prefix counts of the plan, read at the band boundaries): the TILE pipeline's schedule
       const int64_t NB = mh_sym_bands(n);
@@ -685,11 +738,20 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     int64_t ld_ids = 0;
     const uint16_t *ids = mh_dictionary_codes(pwork.p, n, n_hash, &ld_ids);
     DevBuf scratch, entries32, entries;
-    if ((rc = scratch.alloc(mh_sparse_scratch_words(n, n_hash, sp.max_ids, ld_ids) * 4)) != DA_OK) return rc;
-    if ((rc = entries32.alloc((size_t)sp.pairs * 4 + 16)) != DA_OK) return rc;
-    if ((rc = entries.alloc((size_t)sp.pairs * 2 + 16)) != DA_OK) return rc;
-    if ((rc = launch_mh_sparse(ids, ld_ids, n, n_hash, sp.max_ids, sp.pairs, scratch.as<uint32_t>(), entries32.as<uint32_t>(), entries.as<uint16_t>(), d_out, ld,
+    // the route is an optimisation: when its scratch does not fit (or the incidence count exceeds what its 32-bit offsets cover) the
+    // call does not fail -- the dense compare below needs none of it
+    const bool fits = sp.pairs <= 0xfffffff0ull && scratch.alloc(mh_sparse_scratch_words(n, n_hash, sp.max_ids, ld_ids) * 4) == DA_OK &&
+                      entries32.alloc((size_t)sp.pairs * 4 + 16) == DA_OK && entries.alloc((size_t)sp.pairs * 2 + 16) == DA_OK;
+    if (!fits) {
+      (void)hipGetLastError();
+      sp.take = false;
+      if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream, nullptr)) != DA_OK) return rc;
+      route.plane_bits = bits;
+      DA_HIP_TRY(hipEventRecord(ev[2], stream));
+    }
+    else if ((rc = launch_mh_sparse(ids, ld_ids, n, n_hash, sp.max_ids, sp.pairs, scratch.as<uint32_t>(), entries32.as<uint32_t>(), entries.as<uint16_t>(), d_out, ld,
                                stream, ev[3])) != DA_OK) return rc;
+    if (sp.take) {
     DA_HIP_TRY(hipEventRecord(ev[4], stream));
     DA_HIP_TRY(hipStreamSynchronize(stream));
     route.taken = 2;
@@ -699,6 +761,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     (void)hipEventElapsedTime(&route.ms[2], ev[2], ev[3]);
     (void)hipEventElapsedTime(&route.ms[4], ev[3], ev[4]);
     return DA_OK;
+    }
   }
   if (!take) {
     if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, DA_OUT_F64, d_out, ld, stream, bits)) != DA_OK) return rc;
@@ -717,13 +780,13 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   //   rows    K2 on the table, then k_expand_stream: every output row written once from its table row in LDS (no gathered copy)
   //   tiles   K2, column gather (k_gather_columns), tile expansion (k_expand_rows) + diagonal / border tiles, one after the other
   //   rowspipe / pipe   the same kernels with K2 run band by band on a side stream while finished table rows are expanded
-  const char *form_env = getenv("DYNAALIGN_MH_EXPAND");
-  const std::string form = form_env ? form_env : "";
-  const bool may_pipe = !getenv("DYNAALIGN_MH_NO_PIPE") && mh_compare_bands_ok(U, n_hash, bits, dtab.p, ld_d);
+  static const char *const form_names[5] = {"", "rows", "rowspipe", "pipe", "tiles"};
+  const std::string form = form_names[da::config().mh_expand];
+  const bool may_pipe = !da::config().mh_no_pipe && mh_compare_bands_ok(U, n_hash, bits, dtab.p, ld_d);
   if ((form.empty() || form == "rows" || form == "rowspipe") && expand_stream_ok(n, U, n_hash, d_out, ld)) {
     DevBuf lists;
     if ((rc = lists.alloc(expand_stream_scratch_bytes(n, U))) != DA_OK) return rc;
-    if (form != "rows" && may_pipe) {
+    if (form != "rows" && may_pipe) do {
       // the row expansion PIPELINED with K2: the first `head` bands of the table at full occupancy, the rest by the persistent kernel with `wg`
       // workgroup(s) per CU on a side stream (one 36 KB ring fits beside the expansion's 94 KB row) while the finished table rows are expanded
       const int64_t KB = mh_sym_bands(U);
@@ -731,15 +794,15 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       // and a slower K2 wants a head start and smaller chunks (profiles/r03_m_pipeline_rows_*.txt: head x step sweeps for both)
       const bool two = expand_stream_packed(n_hash);
       int wg = two ? 2 : 1, head = two ? 1 : 4, step = two ? 8 : 4;
-      if (const char *e = getenv("DYNAALIGN_MH_PIPE_STEP")) step = std::max(1, atoi(e));
-      if (const char *e = getenv("DYNAALIGN_MH_PIPE_WG")) wg = std::max(1, std::min(4, atoi(e)));
-      if (const char *e = getenv("DYNAALIGN_MH_PIPE_HEAD")) head = std::max(1, atoi(e));
-      const bool alt = !getenv("DYNAALIGN_MH_PIPE_ONE_STREAM");
+      if (da::config().mh_pipe_step > 0) step = da::config().mh_pipe_step;       // DYNAALIGN_MH_PIPE_STEP / _WG / _HEAD / _ONE_STREAM: schedule experiments
+      if (da::config().mh_pipe_wg > 0) wg = da::config().mh_pipe_wg;
+      if (da::config().mh_pipe_head > 0) head = da::config().mh_pipe_head;
+      const bool alt = !da::config().mh_pipe_one_stream;
       std::vector<int64_t> cuts{0};
       while (cuts.back() < KB) cuts.push_back(std::min(KB, cuts.back() + (cuts.size() == 1 ? head : step)));
       const size_t C = cuts.size() - 1;
       PipeRes *pr = pipe_acquire(3 * C + 1);
-      if (!pr) return fail(DA_ERR_HIP, "pipelined duplicate route: no side stream");
+      if (!pr) break;   // no side stream / events to be had: the one-stream form below needs none
       struct PipeGuard { PipeRes *r; ~PipeGuard() { (void)hipStreamSynchronize(r->side); (void)hipStreamSynchronize(r->alt[0]); (void)hipStreamSynchronize(r->alt[1]); pipe_release(r); } } pguard{pr};
       hipEvent_t *pe = pr->ev.data();                                // per chunk: table rows done, rows begin / end; [3 C]: lists done
       // beside the first band on the side stream: the table's diagonal / border tiles and the copy lists, both on the caller's stream
@@ -774,7 +837,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
         if (e > covered_to) { route.ms[4] += e - std::max(b, covered_to); covered_to = e; }
       }
       return DA_OK;
-    }
+    } while (0);
     if ((rc = launch_mh_compare(planes.as<uint32_t>(), U, n_hash, 0, U, true, DA_OUT_COMPACT, dtab.p, ld_d, stream, bits)) != DA_OK) return rc;
     DA_HIP_TRY(hipEventRecord(ev[3], stream));
     if ((rc = launch_expand_stream(dtab.as<uint16_t>(), ld_d, p.uidx, n, U, n_hash, d_out, ld, lists.p, stream, ev[4])) != DA_OK) return rc;
@@ -790,7 +853,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     return DA_OK;
   }
   if ((rc = ftab.alloc(expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0))) != DA_OK) return rc;
-  if (form != "tiles" && !ub.empty() && may_pipe) {
+  if (form != "tiles" && !ub.empty() && may_pipe) do {
     // PIPELINED form.  The table is compared band by band (1024 unique rows each, in order) by the persistent kernel on
     // a side stream with only `wg` workgroups per CU, so the rest of every CU stays free; the output row bands whose strings are all
     // numbered below the finished table rows are gathered (on `stream`) and expanded (on two alternating streams: chunk c + 1 fills
@@ -798,9 +861,9 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     // occurrence, so both sweep their triangles in the same direction and the compare stays ahead.  Same kernels, same bits.
     const int64_t KB = mh_sym_bands(U), NB = (int64_t)ub.size() - 1, ld_f = ceil_div(n, 8) * 8;
     int step = 4, wg = 2;
-    if (const char *e = getenv("DYNAALIGN_MH_PIPE_STEP")) step = std::max(1, atoi(e));
-    if (const char *e = getenv("DYNAALIGN_MH_PIPE_WG")) wg = std::max(1, std::min(4, atoi(e)));
-    const bool alt = !getenv("DYNAALIGN_MH_PIPE_ONE_STREAM");
+    if (da::config().mh_pipe_step > 0) step = da::config().mh_pipe_step;
+    if (da::config().mh_pipe_wg > 0) wg = da::config().mh_pipe_wg;
+    const bool alt = !da::config().mh_pipe_one_stream;
     struct Chunk { int64_t kb0, kb1, ob0, ob1; };
     std::vector<Chunk> chunks;
     for (int64_t kb = 0, ob = 0; kb < KB;) {
@@ -813,7 +876,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     }
     const size_t C = chunks.size();
     PipeRes *pr = pipe_acquire(5 * C);
-    if (!pr) return fail(DA_ERR_HIP, "pipelined duplicate route: no side stream");
+    if (!pr) break;   // no side stream / events to be had: the one-stream form below needs none
     // leaves the side streams idle before the buffers declared above go back to the cache (error returns included)
     struct PipeGuard { PipeRes *r; ~PipeGuard() { (void)hipStreamSynchronize(r->side); (void)hipStreamSynchronize(r->alt[0]); (void)hipStreamSynchronize(r->alt[1]); pipe_release(r); } } pguard{pr};
     hipEvent_t *pe = pr->ev.data();                                  // per chunk: table rows done, gather begin / end, rows begin / end
@@ -857,7 +920,7 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     }
     (void)hipEventElapsedTime(&route.ms[5], ev[5], ev[6]);
     return DA_OK;
-  }
+  } while (0);
   if ((rc = launch_mh_compare(planes.as<uint32_t>(), U, n_hash, 0, U, true, DA_OUT_COMPACT, dtab.p, ld_d, stream, bits)) != DA_OK) return rc;
   DA_HIP_TRY(hipEventRecord(ev[3], stream));
   if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, DA_OUT_F64, false, n_hash, d_out, ld, stream, 0, ftab.as<uint16_t>(),
@@ -1040,9 +1103,9 @@ static int nw_full_symmetric(const uint8_t *d_codes, const int64_t *d_offsets, i
   for (auto &e : ev) DA_HIP_TRY(hipEventCreate(&e));
   DA_HIP_TRY(hipEventRecord(ev[0], stream));
   int64_t min_n = 2048;
-  if (const char *e = getenv("DYNAALIGN_NW_DEDUP_MIN_N")) min_n = atoll(e);   // tests lower it to reach the route with tiny inputs
+  if (da::config().nw_dedup_min_n >= 0) min_n = da::config().nw_dedup_min_n;   // DYNAALIGN_NW_DEDUP_MIN_N: tests lower it to reach the route with tiny inputs
   const bool eligible = n >= min_n && n <= 0x7ffffff0LL && max_len <= 64 && max_len >= 1 && (kind == DA_OUT_F64 || kind == DA_OUT_COMPACT) &&
-                        gap_open >= 0 && gap_ext >= 0 && !getenv("DYNAALIGN_NW_NO_DEDUP");
+                        gap_open >= 0 && gap_ext >= 0 && !da::config().nw_no_dedup;
   if (eligible) {
     DevBuf work;
     if ((rc = work.alloc(nw_dedup_workspace_bytes(n, total))) != DA_OK) return rc;
@@ -1680,7 +1743,7 @@ static int mh_host_common(const uint8_t *residues, const int64_t *offsets, int64
     DA_HIP_TRY(hipStreamSynchronize(nullptr));   // the workspace is released here
   }
   tr.mark("signatures + codes");
-  if (kind == DA_OUT_F64 && row_begin == 0 && row_end == n && rows_per_block(n, sizeof(uint16_t)) >= n && !getenv("DYNAALIGN_NO_HOST_WIDEN")) {
+  if (kind == DA_OUT_F64 && row_begin == 0 && row_end == n && rows_per_block(n, sizeof(uint16_t)) >= n && !da::config().no_host_widen) {
     // the float64 matrix for a HOST caller: counts (uint16) leave the device, a quarter of the bytes over PCIe, and the host
     // widens them while copying -- count / n_hash is the same IEEE divide here as on the device (src/minHash.cpp:174)
     DevBuf dcnt;
@@ -1781,7 +1844,7 @@ static int nw_host_common(const uint8_t *residues, const int64_t *offsets, int64
 
   const int64_t rows_total = row_end - row_begin;
   if (out_f64 && row_begin == 0 && row_end == n && max_len <= 127 && rows_per_block(n, sizeof(uint16_t)) >= n &&
-      !getenv("DYNAALIGN_NO_HOST_WIDEN")) {
+      !da::config().no_host_widen) {
     // as for similarityMH: the (matches << 8 | length) codes cross PCIe and the host divides (src/pairwiseSeqAlign.cpp:311)
     DevBuf dcode;
     if ((rc = dcode.alloc((size_t)n * (size_t)n * sizeof(uint16_t))) != DA_OK) return rc;
@@ -1891,6 +1954,7 @@ struct Rccl {
   void *h = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;              // optional: tears down a communicator whose collective may be stuck
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
@@ -1904,6 +1968,7 @@ struct Rccl {
     if (!h) return false;
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(h, "ncclCommAbort"));
     AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(h, "ncclAllGather"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     if (!CommInitAll || !CommDestroy || !AllGather || !GetErrorString) { why = "librccl lacks ncclCommInitAll / ncclAllGather"; h = nullptr; return false; }
@@ -2006,8 +2071,21 @@ int parse_opts(const da_opts *o, Multi &m) {
   return DA_OK;
 }
 
-// the communicators stay cached (destroy_cached_comms); the call only gives up its right to use them
-void destroy_comms(Multi &m) {
+// the communicators stay cached (destroy_cached_comms); the call only gives up its right to use them.  `failed`: some rank of this
+// call returned an error -- a communicator that has seen a failed or abandoned collective may hang the next one, so the cache entry of
+// this device list is torn down (ncclCommAbort where the library has it) before the lock is released; the next call makes new ones.
+size_t g_comm_evictions = 0;                        // (tests: da_debug_comm_cache_state)
+void destroy_comms(Multi &m, bool failed = false) {
+  if (failed && m.exchange == DA_EXCHANGE_ALLGATHER && m.comm_use.owns_lock()) {
+    std::lock_guard<std::mutex> g(rccl_mutex());
+    auto it = comm_cache().find(m.devs);
+    if (it != comm_cache().end()) {
+      for (auto c : it->second)
+        if (c) (void)(rccl().CommAbort ? rccl().CommAbort(c) : rccl().CommDestroy(c));
+      comm_cache().erase(it);
+      ++g_comm_evictions;
+    }
+  }
   m.comms.clear();
   if (m.comm_use.owns_lock()) m.comm_use.unlock();
 }
@@ -2044,7 +2122,9 @@ template <typename F> int run_ranks(Multi &m, const da_opts *o, F body) {
     for (auto &t : th) t.join();
   }
   (void)hipSetDevice(cur);
-  destroy_comms(m);
+  bool any_failed = false;
+  for (int p = 0; p < m.P; ++p) any_failed = any_failed || m.rc[p] != DA_OK;
+  destroy_comms(m, any_failed);
   if (o && o->struct_size >= sizeof(da_opts) && o->phase_ms) {
     for (int k = 0; k < PH_COUNT; ++k) {
       double mx = 0.0;
@@ -2091,6 +2171,16 @@ size_t destroy_cached_comms() {
 }  // namespace da
 
 extern "C" {
+
+/* tests: {cached device lists, evictions after a failed ALLGATHER call}; with force_fail != 0 the NEXT DA_EXCHANGE_ALLGATHER call's rank 0
+ * fails right after its compute phase (before the collective) -- every rank then skips the exchange and the cache entry must go */
+static std::atomic<int> g_force_exchange_error{0};
+int da_debug_comm_cache_state(int force_fail, size_t *out2) {
+  std::lock_guard<std::mutex> u(da::comm_use_mutex());
+  if (out2) { out2[0] = da::comm_cache().size(); out2[1] = da::g_comm_evictions; }
+  if (force_fail) g_force_exchange_error.store(1);
+  return DA_OK;
+}
 
 int da_rccl_available(void) {
   std::lock_guard<std::mutex> g(rccl_mutex());
@@ -2172,6 +2262,8 @@ int da_similarity_mh_opts(const uint8_t *residues, const int64_t *offsets, int64
     } while (0);
     m.ms[p][PH_COMPUTE] = now_ms() - t;
     m.block[p] = pk.p;
+    if (p == 0 && rc == DA_OK && m.exchange == DA_EXCHANGE_ALLGATHER && g_force_exchange_error.exchange(0))   // (test hook, da_debug_comm_cache_state)
+      rc = fail(DA_ERR_HIP, "forced exchange failure (test hook)");
     ok = m.bar->arrive(rc == DA_OK);                 // every block is complete (and nobody failed) before anyone exchanges
     if (!ok) return rc;
     t = now_ms();

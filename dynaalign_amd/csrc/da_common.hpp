@@ -12,6 +12,35 @@
 #include "../../include/dynaalign.h"
 
 namespace da {
+// ---- run-time switches --------------------------------------------------------------------------------------------------------
+// Every DYNAALIGN_* environment variable the library honours, parsed ONCE (first use) into this struct; INTEGRATION.md lists them.
+// They select between routes / kernels that produce identical bits (tests and A / B timings use them) or size host-side resources;
+// none changes a result.  da_config_reload() (a test hook, also called by the Python mirror when the process environment changed)
+// parses the environment again; library code never calls getenv.
+struct Config {
+  // similarityMH routes (api.cpp mh_full_symmetric)
+  bool mh_no_dedup = false, mh_no_sparse = false, mh_no_pipe = false, mh_pipe_one_stream = false;
+  int64_t mh_dedup_min_n = -1, mh_dedup_max_pct = -1;      // -1: the built-in rule
+  uint64_t mh_sparse_max_pairs = 400000000ull;
+  int mh_expand = 0;                                       // 0 default (first form whose shape test passes), 1 rows, 2 rowspipe, 3 pipe, 4 tiles
+  int mh_pipe_step = 0, mh_pipe_wg = 0, mh_pipe_head = 0;  // 0: the built-in schedule
+  int plane_bits = 0;                                      // lower bound on the code planes: 0 / 12 / 14 / 15 / 16, 32 = raw signature bits
+  // compare kernels
+  bool k2_no_asm = false, k2_persist = false;
+  int k2_wg_per_cu = 0;
+  // similarityNW
+  bool nw_no_dedup = false, nw_int32 = false, nw_no_asm = false;
+  int64_t nw_dedup_min_n = -1;
+  // host-pointer boundary
+  bool no_host_widen = false, plain_d2h = false, no_buffer_cache = false;
+  int d2h_threads = 0, buffer_cache_pct = 30;
+  uint64_t block_bytes = 0;                                // 0: half of the free device memory
+  // diagnostics / host clustering
+  bool trace = false, louvain_debug = false;
+  int louvain_threads = 0;
+};
+const Config &config();
+
 
 // thread-local message behind da_last_error()
 std::string &last_error_ref();
@@ -129,8 +158,9 @@ int launch_mh_sparse(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_ha
                      uint32_t *d_entries32, uint16_t *d_entries, double *d_out, int64_t ld, hipStream_t stream, hipEvent_t after_buckets = nullptr);
 // dict_kernels.hip: where the codes of launch_mh_dictionary sit in its workspace ([n_hash][*ld_ids] uint16, 0xFFFF = value seen once)
 const uint16_t *mh_dictionary_codes(const void *d_work, int64_t n, int n_hash, int64_t *ld_ids);
-// frees the idle scratch instances of the role-split compare kernel (da_release_device_memory); returns the bytes freed
-size_t release_compare_scratch();
+#ifdef DA_K2_EXPERIMENTS
+size_t release_compare_scratch();   // (experiment library only: idle scratch of the role-split compare kernel)
+#endif
 // dict_kernels.hip: signatures -> compare operand.  Dictionary codes (8 / 12 / 16 planes per group,
 // whatever the largest column dictionary needs) are exact for n <= DA_DICT_MAX_N; *d_status_out
 // points at two ints in the workspace ({error, largest id count}), valid once the stream has drained.

@@ -67,7 +67,7 @@ struct Mt19937 {   // ISO C++ [rand.predef] mt19937, restated (std::shuffle / un
 // the local-moving passes.  Nothing the function returns depends on the count (DYNAALIGN_LOUVAIN_THREADS overrides it; 1 = serial).
 int host_threads(int64_t work_items) {
   int t = (int)std::min<int64_t>(16, std::max<int64_t>(1, work_items / 250000));   // (a thread per 250k adjacency entries, at most 16)
-  if (const char *e = getenv("DYNAALIGN_LOUVAIN_THREADS")) t = std::max(1, atoi(e));
+  if (config().louvain_threads > 0) t = config().louvain_threads;   // DYNAALIGN_LOUVAIN_THREADS
   const unsigned hw = std::thread::hardware_concurrency();
   if (hw > 0 && (unsigned)t > hw) t = (int)hw;
   return t;
@@ -292,7 +292,7 @@ int32_t one_level(const Graph &g, double resolution, Mt19937 &rng, std::vector<i
   if (m2 <= 0.0) return n;
 
   // ---- helpers (only worth it on big graphs)
-  const bool debug = getenv("DYNAALIGN_LOUVAIN_DEBUG") != nullptr;
+  const bool debug = config().louvain_debug;
   const int nthreads = host_threads((int64_t)g.adj.size());
   const int nhelp = nthreads - 1;
   constexpr int32_t WINDOW = 512, WINDOW_MIN = 32, WINDOW_MIN_LOG = 4;             // positions of the visiting order the helpers may run ahead: the ring /
@@ -638,7 +638,7 @@ extern "C" int da_louvain_csr(int64_t n_vertices, const int64_t *ptr, const int3
   std::vector<double> k;
   strengths(g0, k);
   for (int64_t v = 0; v < n_vertices; ++v) g0.total += k[(size_t)v];
-  if (getenv("DYNAALIGN_LOUVAIN_DEBUG"))
+  if (config().louvain_debug)
     fprintf(stderr, "[louvain] graph taken from CSR in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
   return run_levels(g0, n_vertices, resolution, seed, membership_out, modularity_out, levels_out);
 }
@@ -657,7 +657,7 @@ extern "C" int da_louvain(int64_t n_vertices, int64_t n_edges, const int32_t *ei
   const auto t_start = std::chrono::steady_clock::now();
   int rc = build_graph(n_vertices, n_edges, ei, ej, ew, g0);
   if (rc != DA_OK) return rc;
-  if (getenv("DYNAALIGN_LOUVAIN_DEBUG"))
+  if (config().louvain_debug)
     fprintf(stderr, "[louvain] graph built in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
   return run_levels(g0, n_vertices, resolution, seed, membership_out, modularity_out, levels_out);
 }

@@ -1404,11 +1404,11 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   // symmetric 12-plane compares: interior tiles by the hand-scheduled kernel, the rest by the general one
   // (float64 output: its count -> double table of n_hash + 1 entries lives in the kernel's 36 KiB ring, K2_A12_TABLE_MAX
   // doubles; a larger n_hash stays with k_mh_compare, which divides directly when its table does not fit)
-  const bool a12 = symmetric && plane_bits == 12 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+  const bool a12 = symmetric && plane_bits == 12 && !config().k2_no_asm && (ld & 1) == 0 &&
                    (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A12_TABLE_MAX) &&
                    (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;   // = a12_takes' alignment test
   // symmetric 16-plane compares likewise (k_mh_compare_a16 on the padded twin of the operand)
-  const bool a16 = symmetric && plane_bits == 16 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+  const bool a16 = symmetric && plane_bits == 16 && !config().k2_no_asm && (ld & 1) == 0 &&
                    (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A16_TABLE_MAX) &&
                    (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;
   if (a16) {
@@ -1424,7 +1424,7 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   // ~13 us either way; with one tile per workgroup that time is spent by an exiting workgroup while the slot's successor
   // already loads.  Kept because it is bit-exact, tested, and the structure the next step needs (stores interleaved into
   // the following tile's stage loop).
-  const bool p12 = a12 && n_hash > K2_GROUP && (kind != DA_OUT_F64 || n_hash < K2_P12_TABLE) && getenv("DYNAALIGN_K2_PERSIST");
+  const bool p12 = a12 && n_hash > K2_GROUP && (kind != DA_OUT_F64 || n_hash < K2_P12_TABLE) && config().k2_persist;
   if (p12) {
     static std::atomic<int> occ_cache[2], cus_cache;              // resident workgroups per CU (4 expected), CUs of the device;
     const int ki = kind == DA_OUT_F64 ? 0 : 1;                    // (atomics: the multi-device entry points launch from several host threads)
@@ -1436,10 +1436,10 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
       hipDeviceProp_t prop;
       DA_HIP_TRY(hipGetDevice(&dev));
       DA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-      if (const char *e = getenv("DYNAALIGN_K2_WG_PER_CU")) occ = atoi(e);
+      if (config().k2_wg_per_cu > 0) occ = config().k2_wg_per_cu;   // DYNAALIGN_K2_WG_PER_CU
       cus_cache.store(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
       occ_cache[ki].store(occ > 0 ? occ : 1);
-      if (getenv("DYNAALIGN_TRACE"))
+      if (config().trace)
         fprintf(stderr, "[dynaalign] k_mh_compare_p12<%s>: %d resident workgroups per CU, %d CUs\n", ki == 0 ? "f64" : "u16", occ_cache[ki].load(), cus_cache.load());
     }
     int wg_per_xcd = occ_cache[ki].load() * ((cus_cache.load() + 7) / 8);
@@ -1476,7 +1476,7 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
       hipLaunchKernelGGL(k_mh_compare_a12<false>, grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd);
   }
   // shard / row-block modes with uint16 output (what the sharded routes compute per rank): the same loop behind the rectangular tile geometry
-  const bool s12 = !symmetric && plane_bits == 12 && kind == DA_OUT_COMPACT && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+  const bool s12 = !symmetric && plane_bits == 12 && kind == DA_OUT_COMPACT && !config().k2_no_asm && (ld & 1) == 0 &&
                    (row_begin % K2_TILE) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 3) == 0;
   if (s12)
     hipLaunchKernelGGL(k_mh_compare_s12, grid, block, 0, stream, d_planes, n, n_hash, row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR,
@@ -1526,7 +1526,7 @@ extern "C" int da_debug_decode_sym_tile(int64_t L, int T, int *ti, int *tj) {
 }
 bool mh_compare_bands_ok(int64_t n, int n_hash, int plane_bits, const void *d_out, int64_t ld) {
   const int64_t T = ceil_div(n, K2_TILE);
-  return plane_bits == 12 && n_hash > K2_GROUP && n_hash <= 65535 && !getenv("DYNAALIGN_K2_NO_ASM") && (ld & 1) == 0 &&
+  return plane_bits == 12 && n_hash > K2_GROUP && n_hash <= 65535 && !config().k2_no_asm && (ld & 1) == 0 &&
          (reinterpret_cast<uintptr_t>(d_out) & 3) == 0 && T * (T + 1) / 2 < 0x7fffffffLL;
 }
 // interior tiles of the bands [band_begin, band_end) by the persistent kernel with at most wg_per_cu resident workgroups per CU:
@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(256, 4) void k_finalize_rows(const void *__restrict
 // the interior tiles go to k_finalize_rows when the geometry allows it; the 64 x 64 kernels then visit only what is left
 static bool finalize_rows_ok(const ShardGeom &geom, const void *d_g, int64_t ld_g, const double *d_out, int64_t ld, bool packed) {
   return geom.tile == 128 && geom.n >= 256 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
-         (reinterpret_cast<uintptr_t>(d_g) & 15) == 0 && (packed || (ld_g & 7) == 0) && !getenv("DYNAALIGN_FINALIZE_NO_FAST");
+         (reinterpret_cast<uintptr_t>(d_g) & 15) == 0 && (packed || (ld_g & 7) == 0);
 }
 
 // Gathered shards -> final matrix.  G holds, for every rank p, its folded local block
@@ -2098,7 +2098,7 @@ void k_expand_stream(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t
 
 bool expand_stream_ok(int64_t n, int64_t U, int n_hash, const void *d_out, int64_t ld) {
   return n >= 2 && n <= 0x7fffffffLL && U >= 1 && U <= 65536 && n_hash >= 1 && n_hash <= 2047 && (ld & 1) == 0 &&
-         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && !getenv("DYNAALIGN_EXPAND_NO_STREAM");
+         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
 }
 extern "C" int da_debug_ratio_check(int n_hash, double *d_out, void *stream) {   // tests: es_ratio(c) for c = 0 .. n_hash into d_out
   if (n_hash < 1 || !d_out) return fail(DA_ERR_BAD_ARG, "ratio check: bad arguments");
@@ -2106,7 +2106,7 @@ extern "C" int da_debug_ratio_check(int n_hash, double *d_out, void *stream) {  
   DA_HIP_TRY(hipGetLastError());
   return DA_OK;
 }
-bool expand_stream_packed(int n_hash) { return n_hash <= 511 && !getenv("DYNAALIGN_EXPAND_STREAM_U16"); }   // counts fit 9 bits: byte + bit plane in LDS
+bool expand_stream_packed(int n_hash) { return n_hash <= 511; }   // counts fit 9 bits: byte + bit plane in LDS
 size_t expand_stream_scratch_bytes(int64_t n, int64_t U) {
   // cnt[U] + cursor[U] (zeroed together), cstart[U + 1], istart[U + 1], cpos[n], items[U + n / ES_COPIES + 1]
   return ((size_t)(4 * U + 8 + ES_TICKETS) * 4 + (size_t)n * 4 + (size_t)(U + n / ES_COPIES + 2) * 8 + 1024);
@@ -2161,7 +2161,6 @@ int launch_expand_stream_rows(const uint16_t *d_D, int64_t ld_d, const int32_t *
   lds = std::max<size_t>(lds, 82 * 1024);
   // one resident workgroup (16 waves) per CU: every workgroup of the grid must be resident from the start (first items are dealt by block index)
   int64_t grid = (int64_t)es_cus.load();
-  if (const char *e = getenv("DYNAALIGN_EXPAND_STREAM_GRID")) grid = std::max(1, atoi(e));
   grid = std::min<int64_t>(grid, (row_end - row_begin) + n / ES_COPIES + 1);
 #define DA_ES(P, Q) hipLaunchKernelGGL((k_expand_stream<P, Q>), dim3((unsigned)grid), dim3(ES_THREADS), lds, stream, d_D, ld_d, d_uidx, L.cstart, L.cpos, L.items, \
                                        L.istart, (int)row_begin, (int)row_end, (int)n, n_hash, d_out, ld, L.ticket + launch_no)
@@ -2183,7 +2182,7 @@ int launch_expand_stream(const uint16_t *d_D, int64_t ld_d, const int32_t *d_uid
 
 // device bytes of the column-gathered table the two-pass expansion wants (0: the shape is not covered, pass NULL)
 size_t expand_rows_workspace_bytes(int64_t n, int64_t U, int kind, bool is_nw, int n_hash, int nw_max_len) {
-  if (kind != DA_OUT_F64 || n < 256 || U > 65536 || U < 1 || getenv("DYNAALIGN_EXPAND_NO_FAST")) return 0;
+  if (kind != DA_OUT_F64 || n < 256 || U > 65536 || U < 1) return 0;
   if (is_nw ? (nw_max_len < 1 || (int64_t)(nw_max_len + 1) * (2 * nw_max_len + 1) > 2048) : (n_hash < 1 || n_hash + 1 > 2048)) return 0;
   return (size_t)U * (size_t)(ceil_div(n, 8) * 8) * 2;
 }
@@ -2663,8 +2662,7 @@ __global__ __launch_bounds__(256, 4) void k_sp_tiles(const uint32_t *__restrict_
 }
 
 size_t mh_sparse_pairs_limit() {
-  if (const char *e = getenv("DYNAALIGN_MH_SPARSE_MAX_PAIRS")) return (size_t)strtoull(e, nullptr, 10);
-  return (size_t)400000000;
+  return (size_t)config().mh_sparse_max_pairs;   // DYNAALIGN_MH_SPARSE_MAX_PAIRS (400 000 000; at most 0xfffffff0: 32-bit entry offsets)
 }
 // stats[0] = matching (pair, hash function) incidences, stats[1] = largest multiplicity of a value in a column; both zeroed here
 int launch_mh_sparse_count(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, unsigned long long *d_stats, hipStream_t stream) {

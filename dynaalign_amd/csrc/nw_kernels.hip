@@ -1124,7 +1124,7 @@ int launch_nw_dedup_count(const uint8_t *d_codes, const int64_t *d_off, int64_t 
   hipLaunchKernelGGL(k_dd_insert, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1);
   hipLaunchKernelGGL(k_dd_lookup, dim3(nb), dim3(256), 0, stream, d_codes, d_off, (int32_t)n, p.table, p.table_size - 1, p.rep, p.mult, p.last);
   hipLaunchKernelGGL(k_dd_flags, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, (int32_t)n, p.fm, p.fs);
-  const bool wide_scan = !getenv("DYNAALIGN_PLAN_SCAN_ONE_WG");   // (diagnostic switch: the single-workgroup scans)
+  const bool wide_scan = true;
   if (n >= 8192 && wide_scan) {     // (the hash table is free again after k_dd_lookup: its words hold the block sums)
     const int32_t nblk = (int32_t)ceil_div(n, 1024);
     uint64_t *bsum = reinterpret_cast<uint64_t *>(p.table);
@@ -1143,7 +1143,7 @@ int launch_nw_dedup_build(const uint8_t *d_codes, const int64_t *d_off, int64_t 
   hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, stream, p.rep, p.mult, p.last, p.pm, p.ps, d_off, (int32_t)n, p.uid_of,
                      p.ufirst, p.ulast, p.ulen, first_order ? 1 : 0);
   hipLaunchKernelGGL(k_dd_map, dim3(nb), dim3(256), 0, stream, p.rep, p.uid_of, (int32_t)n, p.uidx);
-  if (U >= 8192 && !getenv("DYNAALIGN_PLAN_SCAN_ONE_WG")) {
+  if (U >= 8192) {
     const int32_t nblk = (int32_t)ceil_div(U, 1024);
     uint64_t *bsum = reinterpret_cast<uint64_t *>(p.table);
     hipLaunchKernelGGL(k_dd_scan_sums<1>, dim3((unsigned)nblk), dim3(1024), 0, stream, p.ulen, (const int32_t *)nullptr, (int32_t)U, bsum);
@@ -1218,7 +1218,7 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
     return fail(DA_ERR_UNSUPPORTED, "uint16 NW output needs alignment length <= 255 (use the float64 or 32-bit packed kind)");
   // fast path: scores fit the score field of the combined key (see nw_row_ck / CKBits)
   const int64_t gap_span = (int64_t)gap_open + 2 * (max_len <= 32 ? 32 : 64) * (int64_t)gap_ext;
-  const bool ck = gap_open >= 0 && gap_ext >= 0 && gap_span <= (max_len <= 32 ? 7000 : 2500) && !getenv("DYNAALIGN_NW_INT32");
+  const bool ck = gap_open >= 0 && gap_ext >= 0 && gap_span <= (max_len <= 32 ? 7000 : 2500) && !config().nw_int32;
   // <= 32 residues: register-resident lane-per-pair kernel (either cell update);
   // 33..64: the same kernel with the combined key only (the int32 form would need > 256 VGPRs);
   // otherwise the wavefront-per-pair anti-diagonal kernel
@@ -1273,7 +1273,7 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   // ordered mode (the duplicate route's DP), combined-key cell, a generated row block for this NMAX: the hand-scheduled rows (equal to
   // the compiled row within 0.5 %, profiles/r04_c_nw_row_forms_in_kernel.txt; DYNAALIGN_NW_NO_ASM=1: the compiled row).  The direct sweep
   // keeps the compiled row with its row-ahead residue read (2 % faster than the generated rows there).
-  const bool asm_rows = ck && !getenv("DYNAALIGN_NW_NO_ASM");
+  const bool asm_rows = ck && !config().nw_no_asm;
 #define DA_K3(NM)                                                                                                     \
   do {                                                                                                                \
     if constexpr (nw_has_asm_rows<NM>()) {                                                                            \

@@ -14,6 +14,17 @@ from . import _capi
 from ._capi import DA_OUT_COMPACT, DA_OUT_F64
 
 
+def _call(fn, *args):
+    """a library call that allocates on the device: when it runs out of memory, hand PyTorch's cached blocks back to the driver and try
+    once more (the library's own out-of-memory path can only release its own parked buffers; a tensor PyTorch freed -- e.g. the count
+    matrix MinHashSession reserves -- sits in PyTorch's allocator, invisible to hipMalloc)"""
+    rc = fn(*args)
+    if rc == _capi.DA_ERR_NOMEM:
+        torch.cuda.empty_cache()
+        rc = fn(*args)
+    _capi.check(rc)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -82,9 +93,9 @@ def minhash_signatures(ds, k, n_hash, seeds, out=None, planes=None, want_planes=
     ld = sig_ld(n_hash) if n_hash > 0 else 32
     if out is None:
         out = torch.empty((max(ds.n, 1), ld), dtype=torch.int32, device=ds.residues.device)
-    _capi.check(lib.da_dev_minhash_signatures(ds.residues.data_ptr(), ds.offsets.data_ptr(), ds.n, ds.total,
+    _call(lib.da_dev_minhash_signatures, ds.residues.data_ptr(), ds.offsets.data_ptr(), ds.n, ds.total,
                                               ds.max_len, int(k), int(n_hash), seeds.data_ptr(), out.data_ptr(),
-                                              out.stride(0), _stream()))
+                                              out.stride(0), _stream())
     if not want_planes and planes is None:
         return out, None
     return out, mh_planes(out, ds.n, n_hash, planes, work, 32 if raw_planes else min_plane_bits)
@@ -105,9 +116,9 @@ def mh_planes(sig, n, n_hash, planes=None, work=None, min_plane_bits=0):
     if work is None:
         work = torch.empty(planes_workspace_bytes(n, n_hash), dtype=torch.uint8, device=sig.device)
     bits = ctypes.c_int(0)
-    _capi.check(lib.da_dev_mh_planes(sig.data_ptr(), sig.stride(0), n, int(n_hash), int(min_plane_bits),
+    _call(lib.da_dev_mh_planes, sig.data_ptr(), sig.stride(0), n, int(n_hash), int(min_plane_bits),
                                      work.data_ptr(), work.numel(), planes.data_ptr(), planes.numel(),
-                                     ctypes.byref(bits), _stream()))
+                                     ctypes.byref(bits), _stream())
     return Planes(planes, bits.value)
 
 
@@ -133,8 +144,8 @@ def mh_compare(planes, n, n_hash, row_begin=0, row_end=None, symmetric=None, kin
     if symmetric is None:
         symmetric = (row_begin == 0 and row_end == n)
     out = _alloc_out(row_end - row_begin, n, kind, planes.device, out)
-    _capi.check(lib.da_dev_mh_compare(planes.data_ptr(), planes.bits, n, int(n_hash), row_begin,
-                                      row_end, 1 if symmetric else 0, kind, out.data_ptr(), out.stride(0), _stream()))
+    _call(lib.da_dev_mh_compare, planes.data_ptr(), planes.bits, n, int(n_hash), row_begin,
+                                      row_end, 1 if symmetric else 0, kind, out.data_ptr(), out.stride(0), _stream())
     return out
 
 
@@ -144,7 +155,7 @@ def nw_encode(ds):
     _require_cuda(ds.residues, "residues")
     ds.codes = torch.empty_like(ds.residues)
     bad = torch.zeros(1, dtype=torch.int32, device=ds.residues.device)
-    _capi.check(lib.da_dev_nw_encode(ds.residues.data_ptr(), ds.total, ds.codes.data_ptr(), bad.data_ptr(), _stream()))
+    _call(lib.da_dev_nw_encode, ds.residues.data_ptr(), ds.total, ds.codes.data_ptr(), bad.data_ptr(), _stream())
     return bad
 
 
@@ -167,15 +178,15 @@ def nw(ds, matrix_name="BLOSUM62", gap_open=10, gap_ext=4, row_begin=0, row_end=
     if symmetric is None:
         symmetric = (row_begin == 0 and row_end == n)
     out = _alloc_out(row_end - row_begin, n, kind, ds.residues.device, out)
-    _capi.check(lib.da_dev_nw(ds.codes.data_ptr(), ds.offsets.data_ptr(), n, ds.max_len, mid, int(gap_open),
+    _call(lib.da_dev_nw, ds.codes.data_ptr(), ds.offsets.data_ptr(), n, ds.max_len, mid, int(gap_open),
                               int(gap_ext), row_begin, row_end, 1 if symmetric else 0, kind, out.data_ptr(),
                               out.stride(0), None if score is None else score.data_ptr(),
-                              0 if score is None else score.stride(0), _stream()))
+                              0 if score is None else score.stride(0), _stream())
     return out
 
 
 def symmetrize(mat, n, kind=DA_OUT_F64):
-    _capi.check(_capi.load().da_dev_symmetrize(mat.data_ptr(), n, mat.stride(0), kind, _stream()))
+    _call(_capi.load().da_dev_symmetrize, mat.data_ptr(), n, mat.stride(0), kind, _stream())
     return mat
 
 
@@ -184,16 +195,16 @@ def widen(compact, is_nw, n_hash=0, out=None):
     if out is None:
         out = torch.empty(compact.shape, dtype=torch.float64, device=compact.device)
     assert compact.is_contiguous() and out.is_contiguous()
-    _capi.check(_capi.load().da_dev_widen(compact.data_ptr(), out.data_ptr(), compact.numel(), 1 if is_nw else 0,
-                                          int(n_hash), _stream()))
+    _call(_capi.load().da_dev_widen, compact.data_ptr(), out.data_ptr(), compact.numel(), 1 if is_nw else 0,
+                                          int(n_hash), _stream())
     return out
 
 
 def upper_histogram(compact, n, nbins):
     """uint64 histogram (int64 tensor) of the strict upper triangle of an n x n uint16 count matrix."""
     hist = torch.zeros(nbins, dtype=torch.int64, device=compact.device)
-    _capi.check(_capi.load().da_dev_upper_histogram(compact.data_ptr(), compact.stride(0), n, int(nbins),
-                                                    hist.data_ptr(), _stream()))
+    _call(_capi.load().da_dev_upper_histogram, compact.data_ptr(), compact.stride(0), n, int(nbins),
+                                                    hist.data_ptr(), _stream())
     return hist
 
 
@@ -206,9 +217,9 @@ def extract_edges(compact, n, keep, capacity, include_diagonal=True):
     ej = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
     ev = torch.empty(max(capacity, 1), dtype=torch.int16, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    _capi.check(_capi.load().da_dev_extract_edges(compact.data_ptr(), compact.stride(0), n, keep_t.data_ptr(),
+    _call(_capi.load().da_dev_extract_edges, compact.data_ptr(), compact.stride(0), n, keep_t.data_ptr(),
                                                   keep_t.numel(), 1 if include_diagonal else 0, ei.data_ptr(),
-                                                  ej.data_ptr(), ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream()))
+                                                  ej.data_ptr(), ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream())
     return ei, ej, ev, cnt
 
 
@@ -227,15 +238,15 @@ def unique_rows(table, plan, out=None):
     ld = -(-plan.n // 8) * 8
     if out is None:
         out = torch.empty((plan.unique, ld), dtype=torch.int16, device=table.device)
-    _capi.check(lib.da_dev_unique_rows(table.data_ptr(), table.stride(0), plan.ptr(), out.data_ptr(), _stream()))
+    _call(lib.da_dev_unique_rows, table.data_ptr(), table.stride(0), plan.ptr(), out.data_ptr(), _stream())
     return out
 
 
 def upper_histogram_rows(rows, plan, nbins):
     """upper_histogram of the full matrix read through the plan's row map"""
     hist = torch.zeros(nbins, dtype=torch.int64, device=rows.device)
-    _capi.check(_capi.load().da_dev_upper_histogram_rows(rows.data_ptr(), rows.stride(0), plan.c.d_uidx, plan.n, int(nbins),
-                                                         hist.data_ptr(), _stream()))
+    _call(_capi.load().da_dev_upper_histogram_rows, rows.data_ptr(), rows.stride(0), plan.c.d_uidx, plan.n, int(nbins),
+                                                         hist.data_ptr(), _stream())
     return hist
 
 
@@ -247,9 +258,9 @@ def extract_edges_rows(rows, plan, keep, capacity, include_diagonal=True):
     ej = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
     ev = torch.empty(max(capacity, 1), dtype=torch.int16, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    _capi.check(_capi.load().da_dev_extract_edges_rows(rows.data_ptr(), rows.stride(0), plan.c.d_uidx, plan.n, keep_t.data_ptr(),
+    _call(_capi.load().da_dev_extract_edges_rows, rows.data_ptr(), rows.stride(0), plan.c.d_uidx, plan.n, keep_t.data_ptr(),
                                                        keep_t.numel(), 1 if include_diagonal else 0, ei.data_ptr(), ej.data_ptr(),
-                                                       ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream()))
+                                                       ev.data_ptr(), int(capacity), cnt.data_ptr(), _stream())
     return ei, ej, ev, cnt
 
 
@@ -265,8 +276,8 @@ def edges_to_csr(ei, ej, ev, n_edges, n):
     adj = torch.empty(max(2 * m, 1), dtype=torch.int32, device=dev)
     codes = torch.empty(max(2 * m, 1), dtype=torch.int16, device=dev)
     loops = torch.empty(max(n, 1), dtype=torch.int16, device=dev)
-    _capi.check(lib.da_dev_edges_to_csr(ei.data_ptr(), ej.data_ptr(), ev.data_ptr(), m, n, work.data_ptr(), nbytes, ptr.data_ptr(),
-                                        adj.data_ptr(), codes.data_ptr(), loops.data_ptr(), _stream()))
+    _call(lib.da_dev_edges_to_csr, ei.data_ptr(), ej.data_ptr(), ev.data_ptr(), m, n, work.data_ptr(), nbytes, ptr.data_ptr(),
+                                        adj.data_ptr(), codes.data_ptr(), loops.data_ptr(), _stream())
     nnz = int(ptr[n].item())
     return ptr, adj[:nnz], codes[:nnz], loops[:n]
 
@@ -281,8 +292,8 @@ def similarity_mh(ds, k, n_hash, seeds, out=None):
     n = ds.n
     if out is None:
         out = torch.empty((max(n, 1), max(n, 1)), dtype=torch.float64, device=ds.residues.device)
-    _capi.check(lib.da_dev_similarity_mh(ds.residues.data_ptr(), ds.offsets.data_ptr(), n, ds.total, int(k), int(n_hash),
-                                         seeds.data_ptr(), out.data_ptr(), out.stride(0), _stream()))
+    _call(lib.da_dev_similarity_mh, ds.residues.data_ptr(), ds.offsets.data_ptr(), n, ds.total, int(k), int(n_hash),
+                                         seeds.data_ptr(), out.data_ptr(), out.stride(0), _stream())
     return out
 
 
@@ -316,8 +327,8 @@ class UniquePlan:
         self.work = torch.empty(nbytes, dtype=torch.uint8, device=bytes_t.device)
         self.c = _capi.DaUniquePlan()
         self.c.struct_size = ctypes.sizeof(_capi.DaUniquePlan)
-        _capi.check(lib.da_dev_unique_plan(bytes_t.data_ptr(), offsets_t.data_ptr(), int(n), int(total), self.work.data_ptr(), nbytes,
-                                           ctypes.addressof(self.c), _stream()))
+        _call(lib.da_dev_unique_plan, bytes_t.data_ptr(), offsets_t.data_ptr(), int(n), int(total), self.work.data_ptr(), nbytes,
+                                           ctypes.addressof(self.c), _stream())
         self.n, self.unique = int(self.c.n), int(self.c.unique)
 
     def ptr(self):
@@ -329,8 +340,8 @@ def shards_to_table(gathered, ld_g, n, world, value_bits, out=None):
     ld = -(-int(n) // 8) * 8
     if out is None:
         out = torch.empty((int(n), ld), dtype=torch.int16, device=gathered.device)
-    _capi.check(_capi.load().da_dev_shards_to_table(gathered.data_ptr(), int(ld_g), int(n), int(world), int(value_bits), out.data_ptr(),
-                                                    out.stride(0), _stream()))
+    _call(_capi.load().da_dev_shards_to_table, gathered.data_ptr(), int(ld_g), int(n), int(world), int(value_bits), out.data_ptr(),
+                                                    out.stride(0), _stream())
     return out
 
 
@@ -340,8 +351,8 @@ def nw_unique_rows(plan, max_len, matrix_name, gap_open, gap_ext, rank, world, o
     mid = lib.da_matrix_id(matrix_name.encode("latin-1"))
     if mid < 0:
         _capi.check(_capi.DA_ERR_BAD_MATRIX)
-    _capi.check(lib.da_dev_nw_unique_rows(plan.ptr(), int(max_len), mid, int(gap_open), int(gap_ext), int(rank), int(world),
-                                          out_rows.data_ptr(), out_rows.stride(0), _stream()))
+    _call(lib.da_dev_nw_unique_rows, plan.ptr(), int(max_len), mid, int(gap_open), int(gap_ext), int(rank), int(world),
+                                          out_rows.data_ptr(), out_rows.stride(0), _stream())
 
 
 def expand_workspace_bytes(n, unique, is_nw, n_hash=0, nw_max_len=0):
@@ -352,9 +363,9 @@ def expand_unique(table, plan, is_nw, n_hash, nw_max_len, out, table_world=1, wo
     """dense float64 n x n from the table of the unique strings (da_dev_expand_unique)"""
     if work is None:
         work = torch.empty(expand_workspace_bytes(plan.n, plan.unique, is_nw, n_hash, nw_max_len), dtype=torch.uint8, device=table.device)
-    _capi.check(_capi.load().da_dev_expand_unique(table.data_ptr(), table.stride(0), int(table_world), plan.ptr(), 1 if is_nw else 0,
+    _call(_capi.load().da_dev_expand_unique, table.data_ptr(), table.stride(0), int(table_world), plan.ptr(), 1 if is_nw else 0,
                                                   int(n_hash), int(nw_max_len), work.data_ptr(), work.numel(), out.data_ptr(), out.stride(0),
-                                                  _stream()))
+                                                  _stream())
     return out
 
 

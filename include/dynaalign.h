@@ -80,6 +80,16 @@ int da_device_count(void); /* 0 when no HIP device is usable */
  * in the process (e.g. PyTorch's): this call hands everything back.  An allocation of the library's own that would
  * otherwise fail releases the parked buffers first.  Returns the bytes freed. */
 size_t da_release_device_memory(void);
+/* Run-time switches.  The library reads its DYNAALIGN_* environment variables (INTEGRATION.md lists them: route / kernel selection
+ * between forms that produce identical bits, sizes of host-side resources, tracing) ONCE, at its first use, into one struct.
+ * da_config_reload parses the environment again -- a hook for tests and A / B timing scripts that flip a switch inside one process
+ * (the Python mirror calls it by itself when the process's DYNAALIGN_* environment changed since its last call). */
+void da_config_reload(void);
+/* Test hook for the communicator cache of DA_EXCHANGE_ALLGATHER (the communicators of a device list are kept between calls; a call in which
+ * some rank failed destroys its list's entry, since a communicator that saw an abandoned collective may hang the next one):
+ * out2 = {cached device lists, entries destroyed after a failed call}; force_fail != 0 makes rank 0 of the next ALLGATHER call fail
+ * before the collective. */
+int da_debug_comm_cache_state(int force_fail, size_t *out2);
 
 /* ---- HashFamily (reference src/minHash.cpp:67-89) ------------------------ */
 

@@ -10,6 +10,8 @@ import pytest
 
 import oracle_lib as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.fixture(scope="module")
 def lib(built):
@@ -254,3 +256,41 @@ def test_band_ranges_of_the_symmetric_tile_numbering():
                     seen.add((ti.value, tj.value))
         if T <= 64:
             assert len(seen) == T * (T + 1) // 2
+
+
+def test_switches_are_parsed_in_one_place_and_all_documented():
+    """the library's DYNAALIGN_* switches are read once into one struct (api.cpp parse_config); no other product source
+    calls getenv, and INTEGRATION.md section 9 lists exactly the parsed set"""
+    import re
+    csrc = os.path.join(ROOT, "dynaalign_amd", "csrc")
+    api = open(os.path.join(csrc, "api.cpp")).read()
+    body = api[api.index("Config parse_config() {"):api.index("std::atomic<const Config *> g_config")]
+    parsed = set(re.findall(r'"(DYNAALIGN_[A-Z0-9_]+)"', body))
+    assert len(parsed) >= 25
+    for f in os.listdir(csrc):
+        if not f.endswith((".cpp", ".hip", ".hpp")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        src = re.sub(r"#ifdef DA_K2_EXPERIMENTS.*?#endif", "", src, flags=re.S)          # (the experiment twin of the library, tools/experiments/)
+        if f == "api.cpp":
+            src = src.replace(api[api.index("bool env_flag("):api.index("std::atomic<const Config *> g_config")], "")
+        assert "getenv(" not in src, f
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 9. Environment switches"):]
+    table = sec[:sec.index("Read by the host layers")]
+    documented = set()
+    for m in re.finditer(r"`(DYNAALIGN_[A-Z0-9_]+)[=`]|`(_[A-Z_]+)`", table):
+        documented.add(m.group(1) or ("DYNAALIGN_MH_PIPE" + m.group(2)))
+    assert documented == parsed, (sorted(parsed - documented), sorted(documented - parsed))
+
+
+def test_config_reload_hook_is_exported_and_harmless_without_a_gpu():
+    from dynaalign_amd import _capi
+    lib = _capi.load()
+    lib.da_config_reload()
+    os.environ["DYNAALIGN_MH_NO_DEDUP"] = "1"
+    try:
+        assert lib.da_device_count() >= 0                    # (the front end notices the changed environment and reloads by itself)
+    finally:
+        del os.environ["DYNAALIGN_MH_NO_DEDUP"]
+    lib.da_config_reload()

@@ -130,3 +130,95 @@ def test_device_csr_equals_the_host_built_graph(da):
         del os.environ["DYNAALIGN_CLUSTERBREAK_NO_CSR"]
     assert a.calls == b.calls and a.calls > 1
     assert np.array_equal(a["clustered_seq"], b["clustered_seq"]) and a["filtered_seq"] == b["filtered_seq"]
+
+
+def _dense_level_on_device(D, n, n_hash, thresh_p):
+    """R/clusterbreak.R:219-221 applied ON THE DEVICE to a dense float64 similarity matrix D (n x n torch tensor): the type-7 quantile of
+    S[upper.tri(S)] by R's own arithmetic (index = 1 + (M - 1) p, lo / hi order statistics from the exact value histogram -- the
+    similarities take n_hash + 1 values -- qs = (1 - h) x[lo] + h x[hi]), S[S < thr] <- 0, and the graph of the upper triangle incl. the
+    diagonal as a symmetric CSR (both directions of every off-diagonal entry, row-major) + the self-loops.  torch is the checker here,
+    nothing of the library runs in this function.  Returns (thr, n_edges, ptr, adj, codes, loops) -- the last four as device tensors."""
+    import torch
+    dev = D.device
+    hist = torch.zeros(n_hash + 1, dtype=torch.int64, device=dev)
+    step = max(1, min(n, (1 << 28) // max(n, 1)))
+    cols = torch.arange(n, device=dev)
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        blk = D[r0:r1, :n]
+        cnt = torch.round(blk * n_hash).to(torch.int64)
+        assert torch.equal(cnt.to(torch.float64) / n_hash, blk)                      # count / n_hash IS the matrix (src/minHash.cpp:174)
+        upper = cols[None, :] > torch.arange(r0, r1, device=dev)[:, None]            # upper.tri(): strictly above the diagonal
+        hist += torch.bincount(cnt[upper], minlength=n_hash + 1)
+    h = hist.cpu().numpy()
+    M = int(h.sum())
+    assert M == n * (n - 1) // 2
+    cum = np.cumsum(h)
+    values = np.arange(n_hash + 1, dtype=np.float64) / n_hash
+    index = 1.0 + (M - 1) * float(thresh_p)
+    lo, hi = int(np.floor(index)), int(np.ceil(index))
+    x_lo, x_hi = values[np.searchsorted(cum, lo)], values[np.searchsorted(cum, hi)]   # the lo-th / hi-th smallest (1-based)
+    thr = float(x_lo)
+    if index > lo and x_hi != x_lo:
+        thr = (1.0 - (index - lo)) * float(x_lo) + (index - lo) * float(x_hi)
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    adj_parts, code_parts = [], []
+    loops = torch.full((n,), -1, dtype=torch.int16, device=dev)                      # 0xFFFF = no self-loop
+    n_edges = 0
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        blk = D[r0:r1, :n]
+        keep = (~(blk < thr)) & (blk != 0)                                           # S[S < thr] <- 0, then the non-zero entries
+        rows = torch.arange(r0, r1, device=dev)
+        diag = keep[rows - r0, rows]
+        cnt = torch.round(blk * n_hash).to(torch.int16)
+        loops[r0:r1] = torch.where(diag, cnt[rows - r0, rows], loops[r0:r1])
+        n_edges += int(diag.sum().item()) + int((keep & (cols[None, :] > rows[:, None])).sum().item())
+        keep[rows - r0, rows] = False
+        ptr[r0 + 1:r1 + 1] = keep.sum(dim=1)
+        rr, cc = torch.nonzero(keep, as_tuple=True)                                  # row-major = CSR order
+        adj_parts.append(cc.to(torch.int32))
+        code_parts.append(cnt[rr, cc])
+    return thr, n_edges, torch.cumsum(ptr, 0), torch.cat(adj_parts), torch.cat(code_parts), loops
+
+
+def test_config5_first_levels_at_100k_device_edge_path_vs_dense_matrix(da):
+    """BASELINE config 5 at its FULL size, graph level: clusterbreak(size_max = 800, thresh_p = .8) on the 100 000
+    h3n2-like peptides.  The device edge path's first level -- threshold, edge count, the CSR handed to the clustering function
+    (MinHashSession.edges_csr) -- against R's three statements (R/clusterbreak.R:219-221) applied to the dense float64 matrix of
+    da_dev_similarity_mh (itself compared with the oracle by whole rows in test_gpu_fullsize.py), and the same for one deeper level: the
+    subset of the largest first-level cluster (what :246-254 recurses on)."""
+    import torch
+    from dynaalign_amd import device, synth
+    from dynaalign_amd.clusterbreak import louvain_csr
+    from dynaalign_amd.session import MinHashSession
+    n, k, n_hash, seed = 100000, 4, 500, 12345
+    res, off = synth.h3n2_like(n, 20)
+    seqs = synth.to_strings(res, off)
+    sess = MinHashSession(seqs, k, n_hash, seed=seed)
+    thr, n_edges, ptr, adj, codes, loops, values = sess.edges_csr(None, 0.8)
+    assert np.array_equal(values, np.arange(n_hash + 1) / n_hash)
+    member = louvain_csr(n, ptr, adj, codes, loops, values, seed=1)                   # (only to pick the subset of the deeper level)
+    big = np.flatnonzero(member == np.bincount(member).argmax())
+    assert 800 < len(big) < n                                                        # oversize: clusterbreak would recurse on it
+    sub = sess.edges_csr(big, 0.8)
+    torch.cuda.empty_cache()
+    ds = device.DeviceSequences(res, off)
+    D = device.similarity_mh(ds, k, n_hash, da.hash_family_seeds(seed, n_hash))       # dense float64, 80 GB, stays on the device
+    torch.cuda.synchronize()
+
+    def compare(got, Dm, m):
+        g_thr, g_edges, g_ptr, g_adj, g_codes, g_loops = got[:6]
+        w_thr, w_edges, w_ptr, w_adj, w_codes, w_loops = _dense_level_on_device(Dm, m, n_hash, 0.8)
+        assert g_thr == w_thr and g_edges == w_edges
+        assert np.array_equal(g_ptr, w_ptr.cpu().numpy())
+        assert torch.equal(torch.from_numpy(g_adj).to(w_adj.device), w_adj)
+        assert torch.equal(torch.from_numpy(g_codes.view(np.int16)).to(w_codes.device), w_codes)
+        assert np.array_equal(g_loops.view(np.int16), w_loops.cpu().numpy())
+        return w_thr, w_edges
+    t1, e1 = compare((thr, n_edges, ptr, adj, codes, loops), D, n)
+    assert e1 > n and t1 >= 0.0
+    idx = torch.from_numpy(big).to(D.device)
+    Dsub = D.index_select(0, idx).index_select(1, idx).contiguous()                   # similarityMH(sequences[idx]) under the same hash family
+    del D
+    compare(sub, Dsub, len(big))

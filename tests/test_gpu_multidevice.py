@@ -91,3 +91,28 @@ def test_forced_row_block_streaming_in_rows_mode(da, monkeypatch):
     rc, want = O.similarity_mh(seqs, 4, 100, O.seeds(3, 100))
     got = da.similarityMH(seqs, 4, 100, seed=3, devices=[0, 0, 0])
     assert same(got, want)
+
+
+def test_failed_allgather_call_drops_its_cached_communicators(da):
+    """the RCCL communicators of a device list stay cached between calls; a call in which a rank failed must not leave a
+    communicator that saw an abandoned collective behind for the next call.  The test hook makes rank 0 fail before the collective;
+    every rank then skips the exchange, the list's cache entry is destroyed, and the next call builds new communicators and works."""
+    import ctypes
+    from dynaalign_amd import _capi, synth
+    lib = _capi.load()
+    st = (ctypes.c_size_t * 2)()
+    seqs = synth.to_strings(*synth.h3n2_like(400, 20))
+    rc, want = O.similarity_mh(seqs, 4, 100, O.seeds(3, 100))
+    assert rc == 0
+    assert same(da.similarityMH(seqs, 4, 100, seed=3, devices=[0], exchange="allgather"), want)
+    _capi.check(lib.da_debug_comm_cache_state(0, ctypes.addressof(st)))
+    cached, evicted = st[0], st[1]
+    assert cached >= 1
+    _capi.check(lib.da_debug_comm_cache_state(1, ctypes.addressof(st)))
+    with pytest.raises(da.DynaAlignError, match="forced exchange failure"):
+        da.similarityMH(seqs, 4, 100, seed=3, devices=[0], exchange="allgather")
+    _capi.check(lib.da_debug_comm_cache_state(0, ctypes.addressof(st)))
+    assert (st[0], st[1]) == (cached - 1, evicted + 1)
+    assert same(da.similarityMH(seqs, 4, 100, seed=3, devices=[0], exchange="allgather"), want)
+    _capi.check(lib.da_debug_comm_cache_state(0, ctypes.addressof(st)))
+    assert (st[0], st[1]) == (cached, evicted + 1)
