@@ -412,7 +412,6 @@ Config parse_config() {
   c.k2_wg_per_cu = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_K2_WG_PER_CU", 0));
   c.nw_no_dedup = env_flag("DYNAALIGN_NW_NO_DEDUP");
   c.nw_int32 = env_flag("DYNAALIGN_NW_INT32");
-  c.nw_no_asm = env_flag("DYNAALIGN_NW_NO_ASM");
   c.nw_dedup_min_n = env_i64("DYNAALIGN_NW_DEDUP_MIN_N", -1);
   c.no_host_widen = env_flag("DYNAALIGN_NO_HOST_WIDEN");
   c.plain_d2h = env_flag("DYNAALIGN_PLAIN_D2H");

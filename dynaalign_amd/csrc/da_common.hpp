@@ -29,7 +29,7 @@ struct Config {
   bool k2_no_asm = false, k2_persist = false;
   int k2_wg_per_cu = 0;
   // similarityNW
-  bool nw_no_dedup = false, nw_int32 = false, nw_no_asm = false;
+  bool nw_no_dedup = false, nw_int32 = false;
   int64_t nw_dedup_min_n = -1;
   // host-pointer boundary
   bool no_host_widen = false, plain_d2h = false, no_buffer_cache = false;

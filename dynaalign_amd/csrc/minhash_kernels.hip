@@ -2022,6 +2022,9 @@ void k_expand_stream(const uint16_t *__restrict__ D, int64_t ld_d, const int32_t
                                                               int row_end, int n, int n_hash, double *__restrict__ out, int64_t ld,
                                                               uint32_t *__restrict__ ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned char es_lds[];   // the table row
+#ifdef ES_PRIO
+  __builtin_amdgcn_s_setprio(ES_PRIO);   // (experiment: issue priority of the storing waves beside the compare's, which run their loop at priority 2)
+#endif
   uint16_t *row = reinterpret_cast<uint16_t *>(es_lds);
   unsigned char *row_lo = es_lds, *row_hi = row_lo + ld_d;           // (PACKED) ld_d low bytes, then ld_d / 8 bytes of bit 8
   const int tid = threadIdx.x;

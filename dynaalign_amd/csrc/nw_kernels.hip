@@ -173,12 +173,19 @@ __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMA
   }
 }
 
-// Hand-scheduled rows (round 4; tools/gen_nw_asm.py -> nw_rows_p<NMAX>.inc): all DP rows of one sequence1 as ONE asm statement -- two rows
-// per sweep skewed by a column (no copy of the diagonal neighbour), every per-cell operand a VGPR, table reads issued a ring ahead with
-// counted waits.  ASM = true instances exist for the NMAX listed here; the compiled row below serves the rest and the int32 cell.
+// Hand-scheduled rows (round 4; tools/gen_nw_asm.py -> tools/experiments/nw_rows_p<NMAX>.inc): all DP rows of one sequence1 as ONE asm
+// statement -- two rows per sweep skewed by a column (no copy of the diagonal neighbour), every per-cell operand a VGPR, table reads
+// through a ring.  Bit-exact (CPU model: tests/test_nw_asm_model.py; GPU: the test suite run on the experiment library) and NOT faster
+// than the compiled row -- ordered DP 102 vs 97.5 ms, direct sweep 424 vs 417 ms at 100k: the row is bound by its three max-class
+// instructions, not by scheduling (profiles/r04_c_*) -- so the product library does not carry it: ASM = true instances exist only in
+// the experiment twin of the library (tools/experiments/build.sh, -DDA_K2_EXPERIMENTS; DYNAALIGN_NW_ASM=1 selects them there).
+#ifdef DA_K2_EXPERIMENTS
 #include "nw_rows_p12_bind.inc"
 #include "nw_rows_p20_bind.inc"
 template <int NMAX> constexpr bool nw_has_asm_rows() { return NMAX == 12 || NMAX == 20; }
+#else
+template <int NMAX> constexpr bool nw_has_asm_rows() { return false; }
+#endif
 template <int NMAX, bool CK, bool ORD, bool ASM = false>
 __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short(   // <= 24 residues: keep 4 waves per SIMD (128 VGPRs)
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
         }
       }
       typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
+#ifdef DA_K2_EXPERIMENTS
       if constexpr (ASM) {
         static_assert(nw_has_asm_rows<NMAX>(), "no generated row block for this NMAX");
         if (m > 0) {
@@ -361,7 +369,9 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
             NW_ASM_COPY_20
           }
         }
-      } else {
+      } else
+#endif
+      {
       // wave-uniform constants are parked in VGPRs: an SGPR source halves v_bitop3's issue rate
       auto in_vgpr = [](int32_t x) { int32_t v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; };
       const int32_t kx = in_vgpr(((ge - goe) << CK_S2) + (1 << CK_S));   // open a gap from M': -goe, +ge of the frame, priority 1
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
       // a FIXED register that nothing else in the kernel names (with an ordinary "=v" variable a compiler-inserted copy or
       // spill between the two statements would capture a stale value; tests/test_nw_asm_model.py checks the disassembly: v127 appears
       // only in these statements).  LDS operations return in order, so the extra outstanding read only makes the compiler's own
-      // counted lgkmcnt waits stricter.  The ordered mode does not use it (measured slower there; it runs the generated rows anyway).
+      // counted lgkmcnt waits stricter.  The ordered mode does not use it (measured slower there: 98 -> 102 ms).
       constexpr bool PREFETCH = !ORD && NMAX <= 24;
       const uint32_t rc_addr = (uint32_t)(uintptr_t)(lds_u8_t *)&rowcodes[lr][0];
       register uint32_t code_v asm("v127");
@@ -1270,15 +1280,17 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
   dim3 grid((unsigned)ntiles), block(K3_THREADS);
 #define DA_K3_ARGS d_codes, d_off, n, st, (int32_t)gap_open, (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, \
                    d_score, ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast
-  // ordered mode (the duplicate route's DP), combined-key cell, a generated row block for this NMAX: the hand-scheduled rows (equal to
-  // the compiled row within 0.5 %, profiles/r04_c_nw_row_forms_in_kernel.txt; DYNAALIGN_NW_NO_ASM=1: the compiled row).  The direct sweep
-  // keeps the compiled row with its row-ahead residue read (2 % faster than the generated rows there).
-  const bool asm_rows = ck && !config().nw_no_asm;
+#ifdef DA_K2_EXPERIMENTS
+  const bool asm_rows = ck && getenv("DYNAALIGN_NW_ASM");     // experiment library only: the generated rows (tools/gen_nw_asm.py)
+#else
+  const bool asm_rows = false;
+#endif
 #define DA_K3(NM)                                                                                                     \
   do {                                                                                                                \
     if constexpr (nw_has_asm_rows<NM>()) {                                                                            \
-      if (asm_rows && ord_first) {                                                                                    \
-        hipLaunchKernelGGL((k_nw_short<NM, true, true, true>), grid, block, 0, stream, DA_K3_ARGS);                   \
+      if (asm_rows) {                                                                                                 \
+        if (ord_first) hipLaunchKernelGGL((k_nw_short<NM, true, true, true>), grid, block, 0, stream, DA_K3_ARGS);    \
+        else hipLaunchKernelGGL((k_nw_short<NM, true, false, true>), grid, block, 0, stream, DA_K3_ARGS);             \
         break;                                                                                                        \
       }                                                                                                               \
     }                                                                                                                 \

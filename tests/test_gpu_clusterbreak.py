@@ -141,13 +141,16 @@ def _dense_level_on_device(D, n, n_hash, thresh_p):
     import torch
     dev = D.device
     hist = torch.zeros(n_hash + 1, dtype=torch.int64, device=dev)
+    nh = torch.tensor([[float(n_hash)]], dtype=torch.float64, device=dev)
     step = max(1, min(n, (1 << 28) // max(n, 1)))
     cols = torch.arange(n, device=dev)
     for r0 in range(0, n, step):
         r1 = min(n, r0 + step)
         blk = D[r0:r1, :n]
         cnt = torch.round(blk * n_hash).to(torch.int64)
-        assert torch.equal(cnt.to(torch.float64) / n_hash, blk)                      # count / n_hash IS the matrix (src/minHash.cpp:174)
+        # count / n_hash IS the matrix (src/minHash.cpp:174).  (An element-wise tensor / tensor division: torch turns a division by a
+        # Python scalar into a multiplication by its reciprocal, which is not the reference's divide.)
+        assert torch.equal(torch.div(cnt.to(torch.float64), nh.expand_as(blk)), blk)
         upper = cols[None, :] > torch.arange(r0, r1, device=dev)[:, None]            # upper.tri(): strictly above the diagonal
         hist += torch.bincount(cnt[upper], minlength=n_hash + 1)
     h = hist.cpu().numpy()

@@ -39,6 +39,11 @@ if INLOOP:
 if PERSIST:
     SADDR = 1
     REGOUT = 1
+    if "K2ASM_PRIO" not in os.environ and not INLOOP:
+        # the persistent block runs as the band kernel of the pipelined duplicate route, TWO workgroups per CU beside the store-bound row
+        # expansion: at priority 2 its waves issue ahead of the expansion's store instructions and the step is 0.5 ms slower
+        # (16.95 -> 16.45 ms at 100k, profiles/r04_d_pipeline_wave_priorities.txt; raising the expansion to 3 instead: 17.7)
+        PRIO = 0
 PLANES = int(os.environ.get("K2ASM_PLANES", "12"))   # 16: the block of k_mh_compare_a16 (uniform-like data: column dictionaries
 # of up to 65 534 values).  Its operand is a PADDED copy of the 16 code planes: 80-byte LDS slots (64 bytes of planes + 16 of
 # padding) make the loop's 8-byte operand reads bank-conflict-free with plain immediate offsets (the 64-byte slots of the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates dynaalign_amd/csrc/nw_rows_p<NMAX>.inc: the hand-scheduled DP rows of k_nw_short's combined-key cell (nw_kernels.hip,
+"""Generates tools/experiments/nw_rows_p<NMAX>.inc: the hand-scheduled DP rows of k_nw_short's combined-key cell (nw_kernels.hip,
 nw_row_ck; reference src/pairwiseSeqAlign.cpp:238-281) -- all rows 1..m of ONE sequence1 against the lane's sequence2, as ONE
 inline-asm statement with a fixed register map (+ nw_rows_p<NMAX>_bind.inc: the C++ register binding that goes with it).
 
@@ -14,7 +14,7 @@ Structure:
     boundaries; the row's residue code is read a block ahead, read + wait + use inside this one statement (the compiled
     kernel's row-ahead ds_read_u8 relied on register allocation between two statements).
 What round 4 measured with it (profiles/r04_c_nw_row_block_variants.txt, r04_c_nw_row_forms_in_kernel.txt; tools/ubench/nw_rows.hip):
-  * it is NOT faster than the compiled row: 100k h3n2-like, same box: ordered DP 97.6 vs 98.1 ms, direct sweep 424 vs 417 ms.
+  * it is NOT faster than the compiled row (below).
   * the row is bound by its three max-class instructions: with v_max_i32 / v_max3_i32 replaced by v_add_u32 (wrong results) the block
     runs 333 instead of 452 ms per 2*10^12 cells -- 2.2 add-units each, half of the row's time -- while removing ALL table reads and
     address adds changes nothing (461 ms) and neither does the order of the instructions (interleaved or not: 452 / 450).
@@ -23,7 +23,9 @@ What round 4 measured with it (profiles/r04_c_nw_row_block_variants.txt, r04_c_n
     Hence the defaults: ring 2, drained waits (NWASM_WAITS=counted keeps the counted form; the CPU model checks both).
   * v_max_i16 IS full rate but only on the low halves (SDWA / op_sel forms are not: profiles/r04_b_ubench_max16_hi.txt), and the key's
     score must sit in the high bits for the three-way choice -- no 16-bit shortcut for the gap-state maxes.
-k_nw_short uses the block in its ORDERED mode (the duplicate route's DP); the direct sweep keeps the compiled row, 2 % faster there.
+  * in the kernel (same box, same process): ordered DP 102.1 vs 97.5 ms for the compiled row, direct sweep 424 vs 417 ms.
+The product library therefore keeps the compiled row; the block is built into the experiment twin only (tools/experiments/build.sh,
+DYNAALIGN_NW_ASM=1) and stays verified: CPU model (tests/test_nw_asm_model.py) and the GPU suite run on that library.
 
 Register map (VGPR), N = NMAX, R = ring columns (divides N); NWASM_PARITY=1 (default) shifts XP / BO / rings by one register:
   VM[c] = v(c)            best'(r-1, c+1), priority cleared  (outputs: the last row's values)

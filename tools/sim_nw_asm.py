@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU model of csrc/nw_rows_p<NMAX>.inc (the hand-scheduled DP rows of k_nw_short, tools/gen_nw_asm.py).
+"""CPU model of tools/experiments/nw_rows_p<NMAX>.inc (the hand-scheduled DP rows of k_nw_short, tools/gen_nw_asm.py; experiment library only).
 
 Interprets the generated instruction stream for ONE lane: scalar control flow, the VALU subset the block uses, LDS reads.  LDS reads
 return IN ORDER and -- adversarially -- only when a counted `s_waitcnt lgkmcnt(k)` forces them to: a read's destination register is
@@ -221,4 +221,4 @@ def run(inc, nmax, a_codes, b_codes, tabk, go, ge, rc_pad=None, max_steps=2_000_
 
 
 def inc_path(nmax):
-    return os.path.join(ROOT, "dynaalign_amd", "csrc", "nw_rows_p%d.inc" % nmax)
+    return os.path.join(ROOT, "tools", "experiments", "nw_rows_p%d.inc" % nmax)
