@@ -388,7 +388,7 @@ def main():
             e[1].record()
             uplan_, uwork = sharding.mh_unique_local(up, seqs, k, n_hash, d_seeds, rank, world)   # K1 + K1b + this rank's K2 tiles + pack, unique strings
             e[2].record()
-            dist.all_gather_into_tensor(uwork.gathered, uwork.packed)
+            sharding.gather_blocks(uwork.gathered, uwork.packed)
             e[3].record()
             table = device.shards_to_table(uwork.gathered, 0, up.unique, world, uwork.bits)
             e[4].record()
@@ -713,7 +713,7 @@ def main():
             # ordered square and the N x N result is an index expansion (da_nw_last_route: unique count + phase times)
             route = device.nw_last_route()
             nw_obj["route"] = dict(route, note="dedup: DP on the unique strings (ordered square) + expansion; direct: one lane per pair of the input")
-            nw_kernel = "k_nw_short<20, true, %s>" % ("true" if route["dedup"] else "false")    # <NMAX, combined key, ordered mode>
+            nw_kernel = "k_nw_short<20, true, %s, false>" % ("true" if route["dedup"] else "false")    # <NMAX, combined key, ordered mode, generated rows (experiment library only)>
             pm = pmc_kernel(nw_kernel, n)
             bytes_nw = n * L + n * n * 8
             t_dp = route["dp_ms"] * 1e-3 if route["dp_ms"] > 0 else t_nw

@@ -103,13 +103,27 @@ def shared_hash_family(n_hash, seed=None, group=None):
     return hash_family_seeds(shared_seed(seed, group), n_hash)
 
 
+def gather_blocks(gathered, local, group=None):
+    """THE collective of the sharded path: every rank's block (any dtype, contiguous, the same byte size on every rank) into `gathered`
+    (world x that size) -- one all_gather_into_tensor.  NCCL / RCCL and gloo have no 16-bit integer type and an all-gather only moves
+    bytes, so both tensors are viewed as the widest integer type their sizes allow: a 2.8 GB block is 3.5*10^8 int64 elements instead of
+    2.8*10^9 bytes -- counts stay far below 2^31 in every layer (torch, RCCL) whatever they use for them."""
+    nb_l, nb_g = local.numel() * local.element_size(), gathered.numel() * gathered.element_size()
+    assert local.is_contiguous() and gathered.is_contiguous() and nb_g % nb_l == 0, "blocks must be contiguous and of equal size"
+    lb, gb = local.reshape(-1).view(torch.uint8), gathered.reshape(-1).view(torch.uint8)
+    for dt, sz in ((torch.int64, 8), (torch.int32, 4)):
+        if nb_l % sz == 0 and lb.data_ptr() % sz == 0 and gb.data_ptr() % sz == 0:
+            lb, gb = lb.view(dt), gb.view(dt)
+            break
+    dist.all_gather_into_tensor(gb, lb, group=group)
+
+
 def all_pairs_sharded(plan, local_block, gathered, finalize, group=None):
     """local_block: this rank's compact block (tensor [plan.local_rows, ld]) already computed;
     gathered: tensor [world * plan.local_rows, ld]; finalize(gathered) -> result.
     Exactly one collective: all_gather_into_tensor."""
     if plan.world > 1:
-        # NCCL/RCCL and gloo have no 16-bit integer type; an all-gather only moves bytes
-        dist.all_gather_into_tensor(gathered.view(torch.uint8), local_block.view(torch.uint8), group=group)
+        gather_blocks(gathered, local_block, group)
     else:
         gathered.copy_(local_block)
     return finalize(gathered)
@@ -279,7 +293,7 @@ def mh_sharded_step_dedup(uplan, ds, k, n_hash, d_seeds, rank, world, out, group
     if marks is not None:
         marks[0].record()
     if world > 1:
-        dist.all_gather_into_tensor(work.gathered, work.packed, group=group)
+        gather_blocks(work.gathered, work.packed, group)
     else:
         work.gathered.copy_(work.packed)
     if marks is not None:
@@ -309,7 +323,7 @@ def nw_sharded_step_dedup(uplan, max_len, rank, world, out, matrix_name="BLOSUM6
     local = nw_unique_rows_local(uplan, max_len, rank, world, matrix_name, gap_open, gap_ext, out.device)
     if world > 1:
         gathered = torch.empty((world * local.shape[0], local.shape[1]), dtype=torch.int16, device=out.device)
-        dist.all_gather_into_tensor(gathered.view(torch.uint8), local.view(torch.uint8), group=group)
+        gather_blocks(gathered, local, group)
     else:
         gathered = local
     return device.expand_unique(gathered, uplan, True, 0, max_len, out, table_world=world)
