@@ -689,6 +689,86 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_a16(const uint32_t
   }
 }
 
+// ---- the 16-plane loop for the SHARD / row-block modes (uint16 output, no mirror): k_mh_compare_s12's tile geometry in front of
+// k_mh_compare_a16's block (round 4: the per-rank compare of inputs whose column dictionaries need 14 - 16 code bits -- uniform
+// peptides -- ran the compiled kernel).  Takes what s12_takes takes; the compiled kernel keeps diagonal / border tiles (only_edge).
+template <int CODE_BITS>
+__global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_s16(const uint32_t *__restrict__ planes, int64_t n, int n_hash, int64_t row_begin,
+                                                                  int64_t row_end, int tile_stride, int upper_only, int TR, uint16_t *__restrict__ out,
+                                                                  int64_t ld, int fold_q, int64_t fold_w, int band) {
+  constexpr int SLOT = 80, STAGE_BYTES = 2 * K2_TILE * SLOT;
+  __shared__ __attribute__((aligned(16))) uint4 lds_ab[2 * STAGE_BYTES / 16];   // 40 KiB ring
+  const RectTile rt = decode_rect_tile(blockIdx.x, n, row_begin, row_end, tile_stride, upper_only, TR, fold_q, fold_w, band);
+  if (!rt.valid || !s12_takes(rt.I0, rt.J0, n, row_end, ld, rt.Jloc, out)) return;
+  const int64_t I0 = rt.I0, J0 = rt.J0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tx0 = ((wave & 1) << 3) + (lane & 7), ty0 = ((wave >> 1) << 3) + (lane >> 3);
+  // wave-uniform DMA source: wave w stages LDS slots [64w, 64w + 64) = rows (w < 2, row copy) or columns (w >= 2, column copy) of the padded twin
+  const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)wave);
+  const uint32_t nstage = (uint32_t)((n_hash + K2_GROUP - 1) / K2_GROUP), stage_bytes = (uint32_t)(K2_TILE * SLOT);
+  const uint64_t src = reinterpret_cast<uint64_t>(planes) +
+                       4u * (uint64_t)(pad16_base_words(n, n_hash) + (wave_u >= 2 ? pad16_copy_words(n, n_hash) : 0)) +
+                       (uint64_t)((wave_u >= 2 ? J0 : I0) / K2_TILE) * nstage * stage_bytes + (wave_u & 1u) * (64u * SLOT);
+  const uint32_t sl = __builtin_amdgcn_readfirstlane((uint32_t)src), sh = __builtin_amdgcn_readfirstlane((uint32_t)(src >> 32));
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)lds_ab);
+  uint32_t mis[8][4];
+  uint32_t tid_after;
+  {
+    register uint32_t r120 asm("v120") = lds_base + (uint32_t)(ty0 * SLOT);
+    register uint32_t r121 asm("v121") = lds_base + (uint32_t)((K2_TILE + tx0) * SLOT);
+    register uint32_t r124 asm("v124") = (uint32_t)tid * 4u;
+#define K2_CNT(i) register uint32_t c##i asm("v" #i);
+    K2_CNT(64) K2_CNT(65) K2_CNT(66) K2_CNT(67) K2_CNT(68) K2_CNT(69) K2_CNT(70) K2_CNT(71) K2_CNT(72) K2_CNT(73) K2_CNT(74)
+    K2_CNT(75) K2_CNT(76) K2_CNT(77) K2_CNT(78) K2_CNT(79) K2_CNT(80) K2_CNT(81) K2_CNT(82) K2_CNT(83) K2_CNT(84) K2_CNT(85)
+    K2_CNT(86) K2_CNT(87) K2_CNT(88) K2_CNT(89) K2_CNT(90) K2_CNT(91) K2_CNT(92) K2_CNT(93) K2_CNT(94) K2_CNT(95)
+#undef K2_CNT
+#define K2_S16_OPERANDS                                                                                                                      \
+        : "=v"(c64), "=v"(c65), "=v"(c66), "=v"(c67), "=v"(c68), "=v"(c69), "=v"(c70), "=v"(c71), "=v"(c72), "=v"(c73), "=v"(c74),  \
+          "=v"(c75), "=v"(c76), "=v"(c77), "=v"(c78), "=v"(c79), "=v"(c80), "=v"(c81), "=v"(c82), "=v"(c83), "=v"(c84), "=v"(c85),  \
+          "=v"(c86), "=v"(c87), "=v"(c88), "=v"(c89), "=v"(c90), "=v"(c91), "=v"(c92), "=v"(c93), "=v"(c94), "=v"(c95)  \
+        : [lb] "s"(lds_base), [ns] "s"(nstage), [st] "s"(stage_bytes), [wv] "s"(wave_u), [sl] "s"(sl), [sh] "s"(sh),  \
+          "v"(r120), "v"(r121), "v"(r124)  \
+        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v125",  \
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",  \
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",  \
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",  \
+          "v60", "v61", "v62", "v63", "v96", "v97", "v98", "v99",  \
+          "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",  \
+          "v117", "v118", "v119", "v122", "v123"
+    if (CODE_BITS == 14) {
+      asm volatile(
+#include K2_LOOP_INC_14
+          K2_S16_OPERANDS);
+    } else if (CODE_BITS == 15) {
+      asm volatile(
+#include K2_LOOP_INC_15
+          K2_S16_OPERANDS);
+    } else {
+      asm volatile(
+#include K2_LOOP_INC_16
+          K2_S16_OPERANDS);
+    }
+#undef K2_S16_OPERANDS
+    asm volatile("" : "+v"(r124));                               // lane ids are re-derived from the value that crossed the block
+    tid_after = r124 >> 2;
+    const uint32_t cnt[32] = {c64, c65, c66, c67, c68, c69, c70, c71, c72, c73, c74, c75, c76, c77, c78, c79,
+                              c80, c81, c82, c83, c84, c85, c86, c87, c88, c89, c90, c91, c92, c93, c94, c95};
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mis[r][c] = cnt[4 * r + c];
+  }
+  const uint32_t nn = (uint32_t)n_hash * 0x10001u;             // two match counts per register (no borrow: each <= n_hash)
+  const int tid_e = (int)tid_after, wave_e = tid_e >> 6, lane_e = tid_e & 63;
+  const int tx_e = ((wave_e & 1) << 3) + (lane_e & 7), ty_e = ((wave_e >> 1) << 3) + (lane_e >> 3);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    uint16_t *orow = out + (I0 + 32 * (r >> 1) + 2 * ty_e + (r & 1) + rt.Iloc) * ld + (rt.Jloc + J0 + 2 * tx_e);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<uint32_t *>(orow + 32 * g) = nn - mis[r][g];
+  }
+}
+
 // ---- the same 12-plane loop, PERSISTENT: a workgroup walks a sequence of tiles and its DMA ring never drains ----
 // (Opt-in, see launch_mh_compare.)  k_mh_compare_a12 spends 29 % of a workgroup's life outside the plane loop (profiles/r02_b_k2_timeline_*.json: 8.6 us from
 // launch to the loop, 14.5 us of stores, 1.4 us until the slot's next workgroup starts, against 59 us in the loop), so on
@@ -1481,7 +1561,16 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   if (s12)
     hipLaunchKernelGGL(k_mh_compare_s12, grid, block, 0, stream, d_planes, n, n_hash, row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR,
                        static_cast<uint16_t *>(d_out), ld, fold_q, fold_w, band);
-  const int only_edge = (a12 || a16 || s12) ? 1 : 0;
+  // ... and with 14 - 16 code bits (k_mh_compare_a16's block behind the same geometry)
+  const bool s16 = !symmetric && plane_bits == 16 && kind == DA_OUT_COMPACT && !config().k2_no_asm && (ld & 1) == 0 &&
+                   (row_begin % K2_TILE) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 3) == 0;
+  if (s16) {
+#define DA_S16(B) hipLaunchKernelGGL((k_mh_compare_s16<B>), grid, block, 0, stream, d_planes, n, n_hash, row_begin, row_end, tile_stride, upper_only ? 1 : 0, TR, \
+                                     static_cast<uint16_t *>(d_out), ld, fold_q, fold_w, band)
+    if (code_bits == 14) DA_S16(14); else if (code_bits == 15) DA_S16(15); else DA_S16(16);
+#undef DA_S16
+  }
+  const int only_edge = (a12 || a16 || s12 || s16) ? 1 : 0;
   // what is left for the general kernel then: the diagonal tiles + the last tile column, enumerated directly
   if (a12 || a16) grid = dim3((unsigned)(2 * (int64_t)T - 1));
 #define DA_K2(SYM, F64, PL)                                                                              \

@@ -50,21 +50,23 @@ def test_mh_virtual_ranks(da, world, n):
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
 
 
+@pytest.mark.parametrize("bits", [12, 14, 15, 16])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("n,n_hash", [(700, 500), (1300, 96), (1025, 33), (2200, 20)])
-def test_mh_virtual_ranks_hand_scheduled_shard_kernel(da, monkeypatch, world, n, n_hash):
-    """k_mh_compare_s12: the hand-scheduled 12-plane loop behind the shard geometry (cyclic 128-row units, folded rows, upper tiles only) --
-    12 code planes forced (sets this small get 8), interior tiles by it, border tiles by the compiled kernel; every rank's block is
-    bit-identical to the compiled kernel's (poisoned elsewhere), and the finalized matrix to the oracle (reference src/minHash.cpp:119-188)"""
+def test_mh_virtual_ranks_hand_scheduled_shard_kernel(da, monkeypatch, world, n, n_hash, bits):
+    """k_mh_compare_s12 / k_mh_compare_s16<14 | 15 | 16> (round 4): the hand-scheduled plane loops behind the shard geometry (cyclic 128-row
+    units, folded rows, upper tiles only) -- the code-plane count forced (sets this small get 8), interior tiles by them, border tiles by the
+    compiled kernel; every rank's block is bit-identical to the compiled kernel's (poisoned elsewhere), and the finalized matrix to the
+    oracle (reference src/minHash.cpp:119-188)"""
     import os
     from dynaalign_amd import device, sharding, synth
     res, off = synth.h3n2_like(n, 20)
     seqs = synth.to_strings(res, off)
     seeds = da.hash_family_seeds(12345, n_hash)
     ds = device.DeviceSequences(res, off)
-    monkeypatch.setenv("DYNAALIGN_PLANE_BITS", "12")
+    monkeypatch.setenv("DYNAALIGN_PLANE_BITS", str(bits))
     sig, planes = device.minhash_signatures(ds, 4, n_hash, seeds)
-    assert planes.bits == 12
+    assert planes.bits == bits
     plan_of = lambda r: sharding.Plan(n, r, world, sharding.MH_TILE)
     gathered = _gather_virtual(plan_of, lambda p, w: sharding.mh_local_block(p, w, planes, n_hash), world, n)
     monkeypatch.setenv("DYNAALIGN_K2_NO_ASM", "1")
