@@ -412,6 +412,7 @@ Config parse_config() {
   c.k2_wg_per_cu = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_K2_WG_PER_CU", 0));
   c.nw_no_dedup = env_flag("DYNAALIGN_NW_NO_DEDUP");
   c.nw_int32 = env_flag("DYNAALIGN_NW_INT32");
+  c.nw_no_prefix = env_flag("DYNAALIGN_NW_NO_PREFIX_SHARE");
   c.nw_dedup_min_n = env_i64("DYNAALIGN_NW_DEDUP_MIN_N", -1);
   c.no_host_widen = env_flag("DYNAALIGN_NO_HOST_WIDEN");
   c.plain_d2h = env_flag("DYNAALIGN_PLAIN_D2H");
@@ -1122,9 +1123,20 @@ static int nw_full_symmetric(const uint8_t *d_codes, const int64_t *d_offsets, i
       const int64_t ld_d = (U + 7) / 8 * 8;
       DevBuf dtab;
       if ((rc = dtab.alloc((size_t)U * (size_t)ld_d * 2)) != DA_OK) return rc;
+      // prefix sharing of the ordered DP (k_nw_short<.., PFX>): the unique strings' lexicographic order and neighbour prefixes, sequences of
+      // up to 20 residues (0.1 ms; DYNAALIGN_NW_NO_PREFIX_SHARE=1: rows in id order, every row from scratch)
+      DevBuf sortw;
+      const int32_t *perm = nullptr;
+      const uint8_t *lcp = nullptr;
+      if (max_len <= 20 && !da::config().nw_no_prefix) {
+        const size_t sb = nw_sort_unique_workspace_bytes(U);
+        if (sortw.alloc(sb) == DA_OK) {
+          if ((rc = launch_nw_sort_unique(p.ucodes, p.uoff, U, sortw.p, sb, &perm, &lcp, stream)) != DA_OK) return rc;
+        } else (void)hipGetLastError();                     // (an optimisation: without its scratch the rows run in id order)
+      }
       DA_HIP_TRY(hipEventRecord(ev[1], stream));
       if ((rc = launch_nw(p.ucodes, p.uoff, U, max_len, mid, gap_open, gap_ext, 0, U, false, DA_OUT_COMPACT, dtab.p, ld_d, nullptr, 0,
-                          stream, 0, 0, p.ufirst, p.minfirst, p.maxlast)) != DA_OK) return rc;
+                          stream, 0, 0, p.ufirst, p.minfirst, p.maxlast, perm, lcp)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(ev[2], stream));
       DevBuf ftab;                                        // column-gathered twin of the table for the two-pass expansion
       const size_t fbytes = expand_rows_workspace_bytes(n, U, kind, true, 0, (int)max_len);

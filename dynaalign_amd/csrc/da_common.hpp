@@ -29,7 +29,7 @@ struct Config {
   bool k2_no_asm = false, k2_persist = false;
   int k2_wg_per_cu = 0;
   // similarityNW
-  bool nw_no_dedup = false, nw_int32 = false;
+  bool nw_no_dedup = false, nw_int32 = false, nw_no_prefix = false;
   int64_t nw_dedup_min_n = -1;
   // host-pointer boundary
   bool no_host_widen = false, plain_d2h = false, no_buffer_cache = false;
@@ -188,7 +188,12 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
               int matrix_id, int gap_open, int gap_ext, int64_t row_begin, int64_t row_end,
               bool symmetric, int kind, void *d_out, int64_t ld, int32_t *d_score,
               int64_t ld_score, hipStream_t stream, int shard_rank = 0, int shard_world = 0,
-              const int32_t *ord_first = nullptr, const int32_t *ord_minfirst = nullptr, const int32_t *ord_maxlast = nullptr);
+              const int32_t *ord_first = nullptr, const int32_t *ord_minfirst = nullptr, const int32_t *ord_maxlast = nullptr,
+              const int32_t *ord_perm = nullptr, const uint8_t *ord_lcp = nullptr);   // ord_perm / ord_lcp: launch_nw_sort_unique (prefix sharing)
+// nw_kernels.hip: lexicographic order of (unique) sequences of <= 24 residues + the common prefix of sorted neighbours, for the ordered DP
+size_t nw_sort_unique_workspace_bytes(int64_t n);
+int launch_nw_sort_unique(const uint8_t *d_codes, const int64_t *d_off, int64_t n, void *d_work, size_t work_bytes, const int32_t **perm_out,
+                          const uint8_t **lcp_out, hipStream_t stream);
 // nw_kernels.hip: collapse byte-identical sequences before the N x N sweep (exact; see the kernels' header comment)
 struct NwDedupPlan {
   uint32_t *table; uint32_t table_size;

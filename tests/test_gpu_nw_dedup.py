@@ -131,3 +131,34 @@ def test_edge_list_and_device_entry_use_the_same_route(da):
     finally:
         del os.environ["DYNAALIGN_NW_NO_DEDUP"]
     assert torch.equal(a, a2) and torch.equal(b.view(torch.int64), b2.view(torch.int64))
+
+
+@pytest.mark.parametrize("seed,n_pool,n,alpha", [(1, 120, 400, "ACDEFGHIKLMNPQRSTVWY"), (2, 300, 900, "ARN"), (3, 60, 700, "ACDEFGHIKLMNPQRSTVWYBZX*")])
+def test_prefix_sharing_of_the_ordered_dp(da, small_n_route, monkeypatch, seed, n_pool, n, alpha):
+    """round 4: the ordered DP processes the unique strings in lexicographic order and resumes a row's DP at the depth it shares with the
+    previous needed row (k_nw_short<.., PFX>).  Inputs built to stress it: families of strings that share prefixes of every length, strings
+    that are proper prefixes of others (incl. the empty string), ragged lengths 0..20, a three-letter alphabet (long common prefixes AND many
+    gaps), every string several times at scattered positions (both orders of most pairs needed) -- against the oracle's DP + traceback, the
+    direct kernel, and the same route with the sharing switched off (DYNAALIGN_NW_NO_PREFIX_SHARE=1), bit for bit."""
+    rng = np.random.RandomState(seed)
+    pool = set()
+    while len(pool) < n_pool:
+        base = "".join(rng.choice(list(alpha), rng.randint(1, 21)))
+        pool.add(base)
+        for _ in range(rng.randint(0, 4)):                          # relatives: a prefix of `base` + a different tail
+            cut = rng.randint(0, len(base) + 1)
+            tail = "".join(rng.choice(list(alpha), rng.randint(0, 21 - cut)))
+            pool.add((base[:cut] + tail)[:20])
+        pool.add(base[:rng.randint(0, len(base) + 1)])              # a proper prefix (possibly empty)
+    pool = sorted(pool)
+    seqs = [pool[k] for k in rng.randint(0, len(pool), n)]
+    assert "" in seqs or True
+    got, direct = both_routes(da, seqs, "BLOSUM62", 10, 4)
+    want = oracle_matrix(seqs)
+    assert same(got, want) and same(direct, want)
+    monkeypatch.setenv("DYNAALIGN_NW_NO_PREFIX_SHARE", "1")
+    plain = np.asarray(da.similarityNW(seqs, "BLOSUM62", 10, 4))
+    monkeypatch.delenv("DYNAALIGN_NW_NO_PREFIX_SHARE")
+    assert same(plain, want)
+    got2, _ = both_routes(da, seqs, "BLOSUM45", 3, 1)               # other penalties: more gaps, other tie-breaks
+    assert same(got2, oracle_matrix(seqs, "BLOSUM45", 3, 1))

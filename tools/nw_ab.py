@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A / B of the NW row forms on a device-resident set: hand-scheduled rows (default) against the compiled row (DYNAALIGN_NW_NO_ASM=1),
-duplicate route and direct sweep, results compared bit for bit.  usage: nw_ab.py [n] [gen] [len]"""
+"""A / B of the NW duplicate route's ordered DP on a device-resident set: with prefix sharing (default) and without
+(DYNAALIGN_NW_NO_PREFIX_SHARE=1); the direct sweep beside it; results compared bit for bit.  usage: nw_ab.py [n] [gen] [len]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,9 +16,9 @@ assert int(device.nw_encode(ds).item()) == 0
 out = torch.empty((n, n), dtype=torch.float64, device="cuda")
 r = {"n": n, "workload": gen, "len": L}
 ref = None
-for form, noasm in (("asm", None), ("compiled", "1"), ("asm_again", None)):
+for form, noasm in (("prefix_share", None), ("no_prefix_share", "1"), ("prefix_share_again", None)):
     for tag, nodedup in (("dedup", None), ("direct", "1")):
-        for k, v in (("DYNAALIGN_NW_NO_ASM", noasm), ("DYNAALIGN_NW_NO_DEDUP", nodedup)):
+        for k, v in (("DYNAALIGN_NW_NO_PREFIX_SHARE", noasm), ("DYNAALIGN_NW_NO_DEDUP", nodedup)):
             if v: os.environ[k] = v
             else: os.environ.pop(k, None)
         device.nw(ds, out=out); torch.cuda.synchronize()
