@@ -713,7 +713,9 @@ def main():
             # ordered square and the N x N result is an index expansion (da_nw_last_route: unique count + phase times)
             route = device.nw_last_route()
             nw_obj["route"] = dict(route, note="dedup: DP on the unique strings (ordered square) + expansion; direct: one lane per pair of the input")
-            nw_kernel = "k_nw_short<20, true, %s, false>" % ("true" if route["dedup"] else "false")    # <NMAX, combined key, ordered mode, generated rows (experiment library only)>
+            # <NMAX, combined key, ordered mode, generated rows (experiment library only), prefix sharing (ordered mode, <= 20 residues)>
+            pfx = route["dedup"] and ds.max_len <= 20 and not os.environ.get("DYNAALIGN_NW_NO_PREFIX_SHARE")
+            nw_kernel = "k_nw_short<20, true, %s, false, %s>" % ("true" if route["dedup"] else "false", "true" if pfx else "false")
             pm = pmc_kernel(nw_kernel, n)
             bytes_nw = n * L + n * n * 8
             t_dp = route["dp_ms"] * 1e-3 if route["dp_ms"] > 0 else t_nw
