@@ -50,6 +50,7 @@ SIGNATURES = {
     "da_dev_similarity_mh": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "da_mh_last_route": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "da_mh_last_route_chunks": (_i32, [_vp, _vp]),
+    "da_mh_last_route_split": (_i32, [_vp, _vp]),
     "da_dev_unique_plan_bytes": (_sz, [_i64, _i64]),
     "da_dev_unique_plan": (_i32, [_vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp]),
     "da_dev_shards_to_table": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),

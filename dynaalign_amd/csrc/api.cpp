@@ -400,6 +400,9 @@ Config parse_config() {
   c.mh_dedup_min_n = env_i64("DYNAALIGN_MH_DEDUP_MIN_N", -1);
   c.mh_dedup_max_pct = env_i64("DYNAALIGN_MH_DEDUP_MAX_PCT", -1);
   c.mh_sparse_max_pairs = std::min<uint64_t>(env_u64("DYNAALIGN_MH_SPARSE_MAX_PAIRS", 400000000ull), 0xfffffff0ull);   // (32-bit entry offsets)
+  c.mh_no_hybrid = env_flag("DYNAALIGN_MH_NO_HYBRID");
+  c.mh_hybrid_min_n = env_i64("DYNAALIGN_MH_HYBRID_MIN_N", -1);
+  c.mh_hybrid_dedup = env_flag("DYNAALIGN_MH_HYBRID_DEDUP");
   if (const char *e = getenv("DYNAALIGN_MH_EXPAND"))
     c.mh_expand = !strcmp(e, "rows") ? 1 : !strcmp(e, "rowspipe") ? 2 : !strcmp(e, "pipe") ? 3 : !strcmp(e, "tiles") ? 4 : 0;
   c.mh_pipe_step = (int)std::max<int64_t>(0, env_i64("DYNAALIGN_MH_PIPE_STEP", 0));
@@ -537,9 +540,16 @@ static int env_plane_bits() {   // DYNAALIGN_PLANE_BITS: 32 = raw planes, 12 / 1
 // dictionary says the signatures rarely agree (few matching incidences, no large class) build_planes returns with take = true and
 // WITHOUT building the bit planes -- the caller then runs launch_mh_sparse on the dictionary codes in the workspace.
 struct SparseHint { bool take = false; int max_ids = 0; uint64_t pairs = 0, max_mult = 0; };
+// The heavy / rare split (dict_kernels.hip k_hy_split): asked for the same way; when the dictionaries need 12 - 16 code planes but all except a few
+// matching incidences sit on each column's 254 most frequent values, build_planes returns EIGHT planes of dense codes for those (take = true,
+// *bits_out = 8) and leaves the codes of the rare repeated values in the workspace (sparse_codes): the caller runs launch_mh_sparse_lists on them
+// and, after the dense compare, launch_mh_sparse_fixup.
+constexpr int HY_KEEP = 254;
+struct HybridHint { bool take = false; int max_ids = 0, bits_before = 0; uint64_t pairs = 0, max_mult = 0; const uint16_t *sparse_codes = nullptr; int64_t ld_ids = 0; };
 // min_bits: 0 = as few code planes as the data needs, 12 / 16 = at least that many, 32 = raw planes
 static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, int min_bits, void *d_work,
-                        size_t work_bytes, uint32_t *d_planes, int *bits_out, hipStream_t stream, SparseHint *sparse = nullptr) {
+                        size_t work_bytes, uint32_t *d_planes, int *bits_out, hipStream_t stream, SparseHint *sparse = nullptr,
+                        HybridHint *hybrid = nullptr) {
   int rc;
   const int env = env_plane_bits();
   if (env > min_bits) min_bits = env;
@@ -551,27 +561,50 @@ static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_
     int status[2] = {0, 0};
     DA_HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, stream));
     DA_HIP_TRY(hipStreamSynchronize(stream));
-    if (sparse && status[0] == 0 && status[1] >= 1 && status[1] <= 32768 && min_bits == 0 && n >= 2048 && n_hash + 1 <= 2048 &&
-        !da::config().mh_no_sparse) {
-      // how many (pair, hash function) incidences match, and how large is the largest class?  (one more read-back: ~0.15 ms)
+    int bits_data = status[0] == 0 ? mh_plane_bits_for(status[1]) : 32;
+    int64_t hy_min_n = 16384;                                       // below that the compare is too short to pay for the list kernels
+    if (da::config().mh_hybrid_min_n >= 0) hy_min_n = da::config().mh_hybrid_min_n;   // DYNAALIGN_MH_HYBRID_MIN_N (tests lower it)
+    const bool sparse_ok = sparse && status[0] == 0 && status[1] >= 1 && status[1] <= 32768 && min_bits == 0 && n >= 2048 && n_hash + 1 <= 2048 &&
+                           !da::config().mh_no_sparse;
+    const bool hybrid_ok = hybrid && status[0] == 0 && bits_data >= 12 && bits_data <= 16 && min_bits == 0 && status[1] <= 32768 && n >= hy_min_n && n <= 131072 &&
+                           n_hash > 32 && n_hash + 1 <= 2048 && !da::config().mh_no_hybrid && !da::config().k2_no_asm;
+    if (sparse_ok || hybrid_ok) {
+      // how many (pair, hash function) incidences match, and how large is the largest class -- over all repeated values (sparse route) and over the values
+      // outside each column's HY_KEEP most frequent ones (heavy / rare split)?  One kernel, one more read-back (~0.15 ms)
       int64_t ld_ids = 0;
       const uint16_t *ids = mh_dictionary_codes(d_work, n, n_hash, &ld_ids);
       unsigned long long *d_stats = reinterpret_cast<unsigned long long *>(d_status + 4);     // behind the two status words (the workspace ends 256 bytes later)
-      if ((rc = launch_mh_sparse_count(ids, ld_ids, n, n_hash, status[1], d_stats, stream)) != DA_OK) return rc;
-      unsigned long long st[2] = {0, 0};
-      DA_HIP_TRY(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, stream));
+      const uint16_t *dense = nullptr, *rare = nullptr;
+      unsigned long long st[4] = {0, 0, 0, 0};                        // rare incidences, largest rare class, all incidences, largest class
+      if (hybrid_ok) {
+        if ((rc = launch_mh_heavy_split(d_work, n, n_hash, status[1], HY_KEEP, &dense, &rare, d_stats, stream)) != DA_OK) return rc;
+        DA_HIP_TRY(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, stream));
+      } else {
+        if ((rc = launch_mh_sparse_count(ids, ld_ids, n, n_hash, status[1], d_stats, stream)) != DA_OK) return rc;
+        DA_HIP_TRY(hipMemcpyAsync(st + 2, d_stats, 16, hipMemcpyDeviceToHost, stream));
+      }
       DA_HIP_TRY(hipStreamSynchronize(stream));
-      sparse->pairs = st[0]; sparse->max_mult = st[1]; sparse->max_ids = status[1];
-      // admission: the bucket phase costs ~37 ps per incidence (5.1 ms for 1.37e8) and the tile pass ~2.5 ps per pair, the dense compare ~6.3 ps
-      // per pair at n_hash = 500 -- so the route pays while the average number of matches per pair stays below ~0.1 (x n_hash / 500);
-      // plus a memory cap on the bucket and a cap on the class size (a thread walks its class)
       const double pairs_all = 0.5 * (double)n * (double)(n - 1);
-      if (st[0] <= mh_sparse_pairs_limit() && st[1] <= 4096 && (double)st[0] <= pairs_all * (double)n_hash / 5000.0) {
-        sparse->take = true; *bits_out = 0; return DA_OK;
+      if (sparse_ok) {
+        sparse->pairs = st[2]; sparse->max_mult = st[3]; sparse->max_ids = status[1];
+        // admission: the bucket phase costs ~37 ps per incidence (5.1 ms for 1.37e8) and the tile pass ~2.5 ps per pair, the dense compare ~6.3 ps
+        // per pair at n_hash = 500 -- so the route pays while the average number of matches per pair stays below ~0.1 (x n_hash / 500);
+        // plus a memory cap on the bucket and a cap on the class size (a thread walks its class)
+        if (st[2] <= mh_sparse_pairs_limit() && st[3] <= 4096 && (double)st[2] <= pairs_all * (double)n_hash / 5000.0) {
+          sparse->take = true; *bits_out = 0; return DA_OK;
+        }
+      }
+      // heavy / rare split: four to eight planes less = 30 - 47 % of the compare's plane work (~2 ps per pair and 4 planes at n_hash = 500), against
+      // ~37 ps per rare incidence in the list kernels + ~1 ms of fixed cost: taken while the rare values match in < 0.02 of the pairs (x n_hash / 500)
+      if (hybrid_ok && st[0] <= mh_sparse_pairs_limit() && st[1] <= 4096 && (double)st[0] <= pairs_all * (double)n_hash / 25000.0) {
+        hybrid->take = true; hybrid->max_ids = status[1]; hybrid->bits_before = bits_data; hybrid->pairs = st[0]; hybrid->max_mult = st[1];
+        hybrid->sparse_codes = rare; hybrid->ld_ids = ld_ids;
+        *bits_out = 8;
+        return launch_ids_to_planes(d_work, n, n_hash, 8, d_planes, stream, dense);
       }
     }
     if (status[0] == 0) {
-      int bits = mh_plane_bits_for(status[1]);
+      int bits = bits_data;
       if (bits < min_bits) bits = min_bits;
       *bits_out = bits;
       return launch_ids_to_planes(d_work, n, n_hash, bits, d_planes, stream);
@@ -661,7 +694,7 @@ static void pipe_release(PipeRes *r) {
   std::lock_guard<std::mutex> g(pipe_pool().m);
   pipe_pool().idle[r->dev & 63].push_back(r);
 }
-struct MhRoute { int64_t n = 0, unique = 0; int taken = 0, plane_bits = 0, chunks = 0, expand_launches = 0; float ms[6] = {0, 0, 0, 0, 0, 0}; };   // plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles
+struct MhRoute { int64_t n = 0, unique = 0, hybrid_pairs = -1; int taken = 0, plane_bits = 0, chunks = 0, expand_launches = 0, hybrid_bits_before = 0; float ms[6] = {0, 0, 0, 0, 0, 0}; };   // plan, K1 + K1b, K2, column gather, k_expand_rows, diagonal / border tiles
 static MhRoute &mh_route() { static thread_local MhRoute r; return r; }
 
 static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t n, int64_t total, int k, int n_hash,
@@ -729,9 +762,35 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   SparseHint sp;
   // the sparse route is only worth asking about when the input has few duplicates (clustered inputs have large classes: the dense kernels win)
   const bool ask_sparse = !take && U * 10 >= n * 9;
-  if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream, ask_sparse ? &sp : nullptr)) != DA_OK) return rc;
+  // the heavy / rare split (8 dense planes + incidence lists for the rare values): the direct route; the duplicate route's table compare on request
+  HybridHint hy;
+  const bool ask_hybrid = !take || da::config().mh_hybrid_dedup;
+  if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream, ask_sparse ? &sp : nullptr,
+                         ask_hybrid ? &hy : nullptr)) != DA_OK) return rc;
+  DevBuf hy_scratch, hy_entries32, hy_entries;
+  if (hy.take) {
+    // the split is an optimisation: when the lists' scratch does not fit, the planes are rebuilt with all the code bits
+    const bool fits = hy_scratch.alloc(mh_sparse_scratch_words(m, n_hash, hy.max_ids, hy.ld_ids) * 4) == DA_OK &&
+                      hy_entries32.alloc((size_t)hy.pairs * 4 + 16) == DA_OK && hy_entries.alloc((size_t)hy.pairs * 2 + 16) == DA_OK;
+    if (!fits) {
+      (void)hipGetLastError();
+      hy = HybridHint();
+      if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream, nullptr, nullptr)) != DA_OK) return rc;
+    }
+  }
   route.plane_bits = bits;
+  route.hybrid_pairs = hy.take ? (int64_t)hy.pairs : -1;
+  route.hybrid_bits_before = hy.bits_before;
   DA_HIP_TRY(hipEventRecord(ev[2], stream));
+  // lists of the rare values' incidences (tile by tile) and, after a compare, their addition to its result
+  auto hy_lists = [&](hipStream_t st) -> int {
+    return launch_mh_sparse_lists(hy.sparse_codes, hy.ld_ids, m, n_hash, hy.max_ids, hy.pairs, hy_scratch.as<uint32_t>(), hy_entries32.as<uint32_t>(),
+                                  hy_entries.as<uint16_t>(), st);
+  };
+  auto hy_fixup = [&](int kind, void *out, int64_t ld_out, int64_t tr0, int64_t tr1, hipStream_t st) -> int {
+    return launch_mh_sparse_fixup(hy_scratch.as<uint32_t>(), hy_entries.as<uint16_t>(), m, n_hash, hy.max_ids, hy.ld_ids, kind, out, ld_out, tr0, tr1, st);
+  };
+  const int64_t TR_ALL = (m + 127) / 128;
   if (!take && sp.take) {
     // SPARSE route: the signatures rarely agree -- the matching incidences are enumerated from the dictionary codes, bucketed per output
     // tile and every tile written once (exact; minhash_kernels.hip).  ms[2] = link + walk + scan (buckets), ms[4] = the tile pass.
@@ -764,7 +823,17 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     }
   }
   if (!take) {
+    // heavy / rare split: the list kernels (latency-bound, ~0.9 ms at 100k) run on a side stream beside the dense compare; without a side stream, before it
+    PipeRes *pr = hy.take ? pipe_acquire(1) : nullptr;
+    struct PipeGuard { PipeRes *r; ~PipeGuard() { if (r) { (void)hipStreamSynchronize(r->side); pipe_release(r); } } } pguard{pr};
+    if (pr) {
+      DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
+      if ((rc = hy_lists(pr->side)) != DA_OK) return rc;
+      DA_HIP_TRY(hipEventRecord(pr->ev[0], pr->side));
+    } else if (hy.take && (rc = hy_lists(stream)) != DA_OK) return rc;
     if ((rc = launch_mh_compare(planes.as<uint32_t>(), n, n_hash, 0, n, true, DA_OUT_F64, d_out, ld, stream, bits)) != DA_OK) return rc;
+    if (pr) DA_HIP_TRY(hipStreamWaitEvent(stream, pr->ev[0], 0));
+    if (hy.take && (rc = hy_fixup(DA_OUT_F64, d_out, ld, 0, TR_ALL, stream)) != DA_OK) return rc;
     DA_HIP_TRY(hipEventRecord(ev[3], stream));
     DA_HIP_TRY(hipStreamSynchronize(stream));
     (void)hipEventElapsedTime(&route.ms[0], ev[0], ev[1]);
@@ -807,12 +876,17 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       hipEvent_t *pe = pr->ev.data();                                // per chunk: table rows done, rows begin / end; [3 C]: lists done
       // beside the first band on the side stream: the table's diagonal / border tiles and the copy lists, both on the caller's stream
       DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
-      if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, stream)) != DA_OK) return rc;
+      if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, stream, bits)) != DA_OK) return rc;
+      if (hy.take && (rc = hy_lists(stream)) != DA_OK) return rc;
       if ((rc = launch_expand_stream_lists(p.uidx, n, U, lists.p, stream)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(pe[3 * C], stream));
       if (alt) { DA_HIP_TRY(hipStreamWaitEvent(pr->alt[0], pe[3 * C], 0)); DA_HIP_TRY(hipStreamWaitEvent(pr->alt[1], pe[3 * C], 0)); }
       for (size_t c = 0; c < C; ++c) {
-        if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, cuts[c], cuts[c + 1], c == 0 ? 4 : wg, pr->side)) != DA_OK) return rc;
+        if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, cuts[c], cuts[c + 1], c == 0 ? 4 : wg, pr->side, bits)) != DA_OK) return rc;
+        if (hy.take) {     // the rare values' incidences of these tile rows (direct + mirrored elements), once the edge tiles and the lists are there
+          if (c == 0) DA_HIP_TRY(hipStreamWaitEvent(pr->side, pe[3 * C], 0));
+          if ((rc = hy_fixup(DA_OUT_COMPACT, dtab.p, ld_d, cuts[c] * 8, cuts[c + 1] * 8, pr->side)) != DA_OK) return rc;
+        }
         DA_HIP_TRY(hipEventRecord(pe[3 * c], pr->side));
         const hipStream_t es = alt ? pr->alt[c & 1] : stream;
         DA_HIP_TRY(hipStreamWaitEvent(es, pe[3 * c], 0));
@@ -838,7 +912,9 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       }
       return DA_OK;
     } while (0);
+    if (hy.take && (rc = hy_lists(stream)) != DA_OK) return rc;
     if ((rc = launch_mh_compare(planes.as<uint32_t>(), U, n_hash, 0, U, true, DA_OUT_COMPACT, dtab.p, ld_d, stream, bits)) != DA_OK) return rc;
+    if (hy.take && (rc = hy_fixup(DA_OUT_COMPACT, dtab.p, ld_d, 0, TR_ALL, stream)) != DA_OK) return rc;
     DA_HIP_TRY(hipEventRecord(ev[3], stream));
     if ((rc = launch_expand_stream(dtab.as<uint16_t>(), ld_d, p.uidx, n, U, n_hash, d_out, ld, lists.p, stream, ev[4])) != DA_OK) return rc;
     DA_HIP_TRY(hipEventRecord(ev[5], stream));
@@ -881,10 +957,12 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     struct PipeGuard { PipeRes *r; ~PipeGuard() { (void)hipStreamSynchronize(r->side); (void)hipStreamSynchronize(r->alt[0]); (void)hipStreamSynchronize(r->alt[1]); pipe_release(r); } } pguard{pr};
     hipEvent_t *pe = pr->ev.data();                                  // per chunk: table rows done, gather begin / end, rows begin / end
     DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
-    if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, pr->side)) != DA_OK) return rc;
+    if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, pr->side, bits)) != DA_OK) return rc;
+    if (hy.take && (rc = hy_lists(pr->side)) != DA_OK) return rc;
     for (size_t c = 0; c < C; ++c) {
       const Chunk &ch = chunks[c];
-      if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, ch.kb0, ch.kb1, wg, pr->side)) != DA_OK) return rc;
+      if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, ch.kb0, ch.kb1, wg, pr->side, bits)) != DA_OK) return rc;
+      if (hy.take && (rc = hy_fixup(DA_OUT_COMPACT, dtab.p, ld_d, ch.kb0 * 8, ch.kb1 * 8, pr->side)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(pe[5 * c], pr->side));
       DA_HIP_TRY(hipStreamWaitEvent(stream, pe[5 * c], 0));
       DA_HIP_TRY(hipEventRecord(pe[5 * c + 1], stream));
@@ -921,7 +999,9 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     (void)hipEventElapsedTime(&route.ms[5], ev[5], ev[6]);
     return DA_OK;
   } while (0);
+  if (hy.take && (rc = hy_lists(stream)) != DA_OK) return rc;
   if ((rc = launch_mh_compare(planes.as<uint32_t>(), U, n_hash, 0, U, true, DA_OUT_COMPACT, dtab.p, ld_d, stream, bits)) != DA_OK) return rc;
+  if (hy.take && (rc = hy_fixup(DA_OUT_COMPACT, dtab.p, ld_d, 0, TR_ALL, stream)) != DA_OK) return rc;
   DA_HIP_TRY(hipEventRecord(ev[3], stream));
   if ((rc = launch_expand_unique(dtab.as<uint16_t>(), ld_d, p.uidx, n, DA_OUT_F64, false, n_hash, d_out, ld, stream, 0, ftab.as<uint16_t>(),
                                  p.ufirst, U, ev[4], ev[5])) != DA_OK) return rc;
@@ -952,6 +1032,13 @@ int da_mh_last_route_chunks(int *chunks_out, int *expand_launches_out) {
   const MhRoute &r = mh_route();
   if (chunks_out) *chunks_out = r.chunks;
   if (expand_launches_out) *expand_launches_out = r.expand_launches;
+  return DA_OK;
+}
+
+int da_mh_last_route_split(int64_t *rare_incidences_out, int *plane_bits_without_out) {
+  const MhRoute &r = mh_route();
+  if (rare_incidences_out) *rare_incidences_out = r.hybrid_pairs;
+  if (plane_bits_without_out) *plane_bits_without_out = r.hybrid_bits_before;
   return DA_OK;
 }
 

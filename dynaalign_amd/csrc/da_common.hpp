@@ -22,6 +22,8 @@ struct Config {
   bool mh_no_dedup = false, mh_no_sparse = false, mh_no_pipe = false, mh_pipe_one_stream = false;
   int64_t mh_dedup_min_n = -1, mh_dedup_max_pct = -1;      // -1: the built-in rule
   uint64_t mh_sparse_max_pairs = 400000000ull;
+  bool mh_no_hybrid = false, mh_hybrid_dedup = false;                          // heavy / rare split of the column dictionaries (8 dense planes + incidence lists)
+  int64_t mh_hybrid_min_n = -1;                            // -1: the built-in rule
   int mh_expand = 0;                                       // 0 default (first form whose shape test passes), 1 rows, 2 rowspipe, 3 pipe, 4 tiles
   int mh_pipe_step = 0, mh_pipe_wg = 0, mh_pipe_head = 0;  // 0: the built-in schedule
   int plane_bits = 0;                                      // lower bound on the code planes: 0 / 12 / 14 / 15 / 16, 32 = raw signature bits
@@ -148,14 +150,20 @@ int64_t mh_sym_bands(int64_t n);
 int64_t mh_sym_band_prefix(int64_t n, int64_t band);
 bool mh_compare_bands_ok(int64_t n, int n_hash, int plane_bits, const void *d_out, int64_t ld);
 int launch_mh_compare_bands_u16(const uint32_t *d_planes, int64_t n, int n_hash, uint16_t *d_out, int64_t ld, int64_t band_begin,
-                                int64_t band_end, int wg_per_cu, hipStream_t stream);
-int launch_mh_compare_edges_u16(const uint32_t *d_planes, int64_t n, int n_hash, uint16_t *d_out, int64_t ld, hipStream_t stream);
+                                int64_t band_end, int wg_per_cu, hipStream_t stream, int plane_bits = 12);
+int launch_mh_compare_edges_u16(const uint32_t *d_planes, int64_t n, int n_hash, uint16_t *d_out, int64_t ld, hipStream_t stream, int plane_bits = 12);
 // minhash_kernels.hip, SPARSE route of the symmetric float64 compare (inputs whose signatures rarely agree): see the kernels' header comment
 size_t mh_sparse_pairs_limit();
 int launch_mh_sparse_count(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, unsigned long long *d_stats, hipStream_t stream);
 size_t mh_sparse_scratch_words(int64_t n, int n_hash, int max_ids, int64_t ld_ids);
 int launch_mh_sparse(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, uint64_t pairs, uint32_t *d_scratch,
                      uint32_t *d_entries32, uint16_t *d_entries, double *d_out, int64_t ld, hipStream_t stream, hipEvent_t after_buckets = nullptr);
+// ... its list phase alone (k_sp_classes .. k_sp_band: the matching incidences of the codes in d_idsT, bucketed per 128 x 128 tile on or above the
+// diagonal), and the kernel that ADDS those incidences to a finished dense result (heavy / rare split: the dense compare saw the heavy values only)
+int launch_mh_sparse_lists(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_hash, int max_ids, uint64_t pairs, uint32_t *d_scratch,
+                           uint32_t *d_entries32, uint16_t *d_entries, hipStream_t stream);
+int launch_mh_sparse_fixup(const uint32_t *d_scratch, const uint16_t *d_entries, int64_t n, int n_hash, int max_ids, int64_t ld_ids, int kind, void *d_out,
+                           int64_t ld, int64_t tile_row_begin, int64_t tile_row_end, hipStream_t stream);
 // dict_kernels.hip: where the codes of launch_mh_dictionary sit in its workspace ([n_hash][*ld_ids] uint16, 0xFFFF = value seen once)
 const uint16_t *mh_dictionary_codes(const void *d_work, int64_t n, int n_hash, int64_t *ld_ids);
 #ifdef DA_K2_EXPERIMENTS
@@ -170,7 +178,10 @@ int launch_mh_dictionary(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n
                          int **d_status_out, hipStream_t stream);
 int mh_plane_bits_for(int max_ids);
 int launch_ids_to_planes(const void *d_work, int64_t n, int n_hash, int plane_bits, uint32_t *d_planes,
-                         hipStream_t stream);
+                         hipStream_t stream, const uint16_t *d_codes = nullptr);
+// heavy / rare split of the column dictionaries (dict_kernels.hip k_hy_split): dense codes for 8 planes + sparse codes for the incidence lists
+int launch_mh_heavy_split(void *d_work, int64_t n, int n_hash, int max_ids, int keep, const uint16_t **d_dense_out, const uint16_t **d_sparse_out,
+                          unsigned long long *d_stats, hipStream_t stream);
 int launch_sig_to_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, uint32_t *d_planes,
                          hipStream_t stream);
 int launch_finalize_sharded(const uint16_t *d_g, int64_t ld_g, const ShardGeom &geom, bool is_nw, int n_hash,

@@ -19,6 +19,7 @@
 //                     copy, in the blocked order k_mh_compare stages them in (da_common.hpp)
 //   k_sig_to_planes : raw 32-plane operand from sig (n > DA_DICT_MAX_N, or dictionary overflow)
 #include "da_common.hpp"
+#include <atomic>
 
 namespace da {
 namespace {
@@ -178,6 +179,97 @@ __global__ __launch_bounds__(DK_THREADS) void k_dictionary(const uint32_t *__res
   if (tid == 0) atomicMax(status + 1, (int)base);
 }
 
+// -------------------------------------------------- heavy / rare split (round 4) --
+// The bit-sliced compare pays per code PLANE, and a column dictionary of clustered data is very skewed: on the h3n2-like 100k set a column has
+// ~4 000 repeated values, but the 254 most frequent ones carry all but 7*10^6 of the 2.2*10^10 matching (pair, hash function) incidences.  So,
+// exactly:  matches(i, j) = #{h : code equal, code HEAVY in column h} + #{h : code equal, code RARE in column h}
+//   idsD: heavy values -> ranks 0 .. keep-1, everything else 0xFFFF (= the two "never equal" codes of k_ids_to_planes): the dense compare runs on
+//         8 planes instead of 12 - 16;
+//   idsS: rare repeated values keep their dictionary code, everything else 0xFFFF: their incidences are enumerated by the sparse route's list
+//         kernels (minhash_kernels.hip k_sp_classes .. k_sp_band) and added to the dense result by k_hy_fixup.
+// One workgroup per column: LDS histogram of the codes, the count threshold of the `keep` most frequent ones by bisection, ties at the threshold
+// taken in code order until the quota is used up; stats[0] += incidences among rare values, stats[1] = max(largest rare class), stats[2] / [3]: the same
+// over ALL repeated values (what k_sp_count reports: the sparse route's admission test).
+__global__ __launch_bounds__(1024) void k_hy_split(const uint16_t *__restrict__ idsT, int64_t ld_ids, int n, int max_ids, int keep,
+                                                   uint16_t *__restrict__ idsD, uint16_t *__restrict__ idsS, unsigned long long *__restrict__ stats) {
+  extern __shared__ uint32_t hy_hist[];        // max_ids counters (later: ranks), then 1024 partial sums
+  uint32_t *part = hy_hist + max_ids;
+  __shared__ uint32_t red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t *ids = idsT + (int64_t)blockIdx.x * ld_ids;
+  uint16_t *outD = idsD + (int64_t)blockIdx.x * ld_ids, *outS = idsS + (int64_t)blockIdx.x * ld_ids;
+  for (int c = tid; c < max_ids; c += 1024) hy_hist[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const uint32_t c = ids[i];
+    if (c != 0xFFFFu) atomicAdd(&hy_hist[c], 1u);
+  }
+  __syncthreads();
+  auto count_ge = [&](uint32_t t) -> uint32_t {      // how many codes occur at least t times (uniform result)
+    uint32_t k = 0;
+    for (int c = tid; c < max_ids; c += 1024) k += hy_hist[c] >= t;
+    for (int o = 32; o > 0; o >>= 1) k += __shfl_down(k, o);
+    __syncthreads();                                 // (red[] of the previous round has been read by everyone)
+    if (lane == 0) red[wave] = k;
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    return tot;
+  };
+  uint32_t lo = 1, hi = (uint32_t)n + 1u;            // smallest t with count_ge(t) <= keep  (count_ge(n + 1) = 0)
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (count_ge(mid) <= (uint32_t)keep) hi = mid; else lo = mid + 1;
+  }
+  const uint32_t t = lo, above = count_ge(t), quota = (uint32_t)keep - above;    // ties: values seen exactly t - 1 times (>= 2: a repeated value)
+  const bool ties = t >= 3;
+  const int per = (max_ids + 1023) / 1024, c_lo = tid * per, c_hi = c_lo + per < max_ids ? c_lo + per : max_ids;
+  uint32_t f1 = 0, f2 = 0;
+  for (int c = c_lo; c < c_hi; ++c) { const uint32_t m = hy_hist[c]; f1 += m >= t; f2 += ties && m == t - 1; }
+  part[tid] = (f1 << 16) | f2;                       // f1 sums stay <= keep < 2^16, f2 sums <= max_ids <= 2^15
+  __syncthreads();
+  if (tid < 64) {                                    // exclusive scan of the 1024 packed partial sums by one wave (16 each)
+    uint32_t v[16], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { v[q] = part[tid * 16 + q]; tot += v[q]; }
+    uint32_t incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (tid >= o) incl += up; }
+    uint32_t run = incl - tot;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { part[tid * 16 + q] = run; run += v[q]; }
+  }
+  __syncthreads();
+  uint32_t p1 = part[tid] >> 16, p2 = part[tid] & 0xffffu;
+  unsigned long long e = 0, mx = 0, e_all = 0, mx_all = 0;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const uint32_t m = hy_hist[c];
+    uint32_t rank = 0xFFFFu;
+    if (m >= t) rank = p1++;
+    else if (ties && m == t - 1) { if (p2 < quota) rank = above + p2; ++p2; }
+    if (m >= 2) {
+      const unsigned long long inc = (unsigned long long)m * (m - 1) / 2;
+      e_all += inc; mx_all = m > mx_all ? m : mx_all;
+      if (rank == 0xFFFFu) { e += inc; mx = m > mx ? m : mx; }
+    }
+    hy_hist[c] = rank;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    e += __shfl_down(e, o);
+    e_all += __shfl_down(e_all, o);
+    const unsigned long long other = __shfl_down(mx, o), other_all = __shfl_down(mx_all, o);
+    mx = other > mx ? other : mx;
+    mx_all = other_all > mx_all ? other_all : mx_all;
+  }
+  if (lane == 0) { atomicAdd(&stats[0], e); atomicMax(&stats[1], mx); atomicAdd(&stats[2], e_all); atomicMax(&stats[3], mx_all); }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const uint32_t c = ids[i];
+    const uint32_t r = c == 0xFFFFu ? 0xFFFFu : hy_hist[c];
+    outD[i] = (uint16_t)r;
+    outS[i] = (uint16_t)((c != 0xFFFFu && r == 0xFFFFu) ? c : 0xFFFFu);
+  }
+}
+
 // ----------------------------------------------------------- bit planes --
 // 64 sequences x all hash functions per workgroup.  Per chunk of 64 hash functions the 64 x 64
 // uint16 code tile is staged in LDS; a wave then owns a sequence and its lane l holds the code of
@@ -313,6 +405,34 @@ int launch_mh_dictionary(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n
   return DA_OK;
 }
 
+// Heavy / rare split of the dictionary codes (k_hy_split): leaves the dense codes (ranks of the `keep` most frequent values per column) and the
+// sparse codes (the other repeated values) in the workspace's sort scratch -- free once k_dictionary has run -- and two statistics in d_stats
+// (four words, zeroed here): incidences among rare values, largest rare class, incidences among all repeated values, largest class.  The codes of
+// launch_mh_dictionary stay as they are.
+constexpr int HY_MAX_IDS = 32768;
+int launch_mh_heavy_split(void *d_work, int64_t n, int n_hash, int max_ids, int keep, const uint16_t **d_dense_out, const uint16_t **d_sparse_out,
+                          unsigned long long *d_stats, hipStream_t stream) {
+  if (max_ids < 1 || max_ids > HY_MAX_IDS || keep < 1 || keep > 65534 || n > 0x7fffffffLL)
+    return fail(DA_ERR_UNSUPPORTED, "heavy / rare split: too many repeated values per column");
+  const int64_t ldT = dict_ldT(n);
+  const DictWork w = dict_work(d_work, n, n_hash);
+  uint16_t *dense = reinterpret_cast<uint16_t *>(w.sz), *sparse = reinterpret_cast<uint16_t *>(w.si);
+  static std::atomic<uint64_t> attr_done;
+  int dev = 0;
+  DA_HIP_TRY(hipGetDevice(&dev));
+  if (!((attr_done.load() >> (dev & 63)) & 1u)) {
+    DA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hy_split), hipFuncAttributeMaxDynamicSharedMemorySize, (HY_MAX_IDS + 1024) * 4));
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  DA_HIP_TRY(hipMemsetAsync(d_stats, 0, 32, stream));
+  hipLaunchKernelGGL(k_hy_split, dim3((unsigned)n_hash), dim3(1024), (size_t)(max_ids + 1024) * 4, stream, w.idsT, ldT, (int)n, max_ids, keep, dense, sparse,
+                     d_stats);
+  DA_HIP_TRY(hipGetLastError());
+  *d_dense_out = dense;
+  *d_sparse_out = sparse;
+  return DA_OK;
+}
+
 // planes per group that hold `max_ids` dense ids plus the two singleton codes
 // 14 = the 16-plane operand with 14-bit codes (planes 14 and 15 zero): the hand-scheduled kernel then runs seven two-plane steps
 int mh_plane_bits_for(int max_ids) {
@@ -325,9 +445,9 @@ int mh_plane_bits_for(int max_ids) {
 
 // Step 2: codes -> bit planes, `plane_bits` (8 / 12 / 16) planes per group of 32 hash functions
 int launch_ids_to_planes(const void *d_work, int64_t n, int n_hash, int plane_bits, uint32_t *d_planes,
-                         hipStream_t stream) {
+                         hipStream_t stream, const uint16_t *d_codes) {
   const int64_t ldT = dict_ldT(n);
-  const uint16_t *idsT = dict_work(const_cast<void *>(d_work), n, n_hash).idsT;
+  const uint16_t *idsT = d_codes ? d_codes : dict_work(const_cast<void *>(d_work), n, n_hash).idsT;   // d_codes: the dense codes of launch_mh_heavy_split
   hipLaunchKernelGGL(k_ids_to_planes, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, stream, idsT, ldT, n, n_hash,
                      (plane_bits == 14 || plane_bits == 15) ? 16 : plane_bits, plane_bits, d_planes);
   DA_HIP_TRY(hipGetLastError());

@@ -311,7 +311,11 @@ def mh_last_route():
     sparse = t.value == 2
     ch, el = ctypes.c_int(0), ctypes.c_int(0)
     _capi.check(_capi.load().da_mh_last_route_chunks(ctypes.addressof(ch), ctypes.addressof(el)))
-    return {"chunks": ch.value, "expand_launches": el.value, "n": n.value, "unique": n.value if sparse else u.value, "dedup": t.value in (1, 3, 4, 5), "pipelined": t.value in (3, 5),
+    rare, pb0 = ctypes.c_int64(0), ctypes.c_int(0)
+    _capi.check(_capi.load().da_mh_last_route_split(ctypes.addressof(rare), ctypes.addressof(pb0)))
+    # heavy / rare split of the column dictionaries: 8 dense planes + `rare_pairs` incidences added from lists (plane_bits_without: what it replaced)
+    return {"split": rare.value >= 0, "rare_pairs": max(rare.value, 0), "plane_bits_without": pb0.value,
+            "chunks": ch.value, "expand_launches": el.value, "n": n.value, "unique": n.value if sparse else u.value, "dedup": t.value in (1, 3, 4, 5), "pipelined": t.value in (3, 5),
             "expansion": {1: "tiles", 3: "tiles, pipelined", 4: "rows", 5: "rows, pipelined"}.get(t.value, ""), "sparse": sparse,
             "sparse_pairs": u.value if sparse else 0, "plane_bits": b.value, "plan_ms": ms[0], "codes_ms": ms[1],
             "k2_ms": ms[2], "gather_ms": ms[3], "expand_ms": ms[4], "border_ms": ms[5]}

@@ -248,11 +248,20 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
  *                                 (tiles), time some expansion launch was running, diagonal / border tiles} -- the middle three overlap;
  *                                 da_mh_last_route_chunks gives the number of chunks and of expansion launches.
  * All forms write the same bits.
+ * Heavy / rare split (round 4; the direct route, and the duplicate route's table compare with DYNAALIGN_MH_HYBRID_DEDUP=1): when the column
+ * dictionaries need 12 - 16 code planes but nearly all matching incidences sit on each column's 254 most frequent values (clustered data: 7e6 of
+ * 2.2e10 on the h3n2-like 100k set), the bit-sliced compare runs on EIGHT planes of dense codes for those values -- every other value reads as
+ * "never equal" -- and the incidences of the remaining repeated values are enumerated by the sparse route's list kernels and added to the result
+ * (count' = count + m, the float64 element recomputed as (count + m) / n_hash: same division, same bits).  Exact.  Taken when n >= 16384
+ * (DYNAALIGN_MH_HYBRID_MIN_N), 32 < n_hash <= 2047, <= 32768 repeated values per column, the rare incidences number <= n_hash / 25000 per pair on average;
+ * DYNAALIGN_MH_NO_HYBRID=1 disables it.  Then *plane_bits_out = 8 and da_mh_last_route_split gives the number of rare incidences (-1: not taken)
+ * and the plane count the dictionaries would have needed.
  * Any pointer may be NULL. */
 int da_dev_similarity_mh(const uint8_t *d_residues, const int64_t *d_offsets, int64_t n, int64_t total_residues,
                          int k, int n_hash, const uint32_t *d_seeds, double *d_out, int64_t ld, void *stream);
 int da_mh_last_route(int64_t *n_out, int64_t *unique_out, int *dedup_taken_out, int *plane_bits_out, double *ms6_out);
 int da_mh_last_route_chunks(int *chunks_out, int *expand_launches_out);
+int da_mh_last_route_split(int64_t *rare_incidences_out, int *plane_bits_without_out);
 
 /* ---- the pieces of the duplicate-collapsing routes, for callers that orchestrate the steps themselves (the one-process-per-GPU
  * sharded drivers: every rank builds the same plan, computes ITS shard of the unique table with the *_shard / *_unique_rows calls

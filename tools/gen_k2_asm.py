@@ -56,7 +56,13 @@ if PLANES in (14, 15, 16):
     SADDR = 1
     REGOUT = 1
     assert not PERSIST
-SEGS, STEPS = (3, 6) if PLANES == 12 else (5, (PLANES + 1) // 2)   # 16-byte units per LDS slot; 2-plane steps per stage
+# 8: the persistent block on EIGHT code planes (K2ASM_PLANES=8 K2ASM_PERSIST=1 -> k2_loop_p8p.inc; with K2ASM_PRIO=2 -> k2_loop_p8.inc, the
+# one-tile-per-workgroup form): the dense half of the heavy / rare split of the column dictionaries (round 4: the 254 most frequent
+# values of a column keep dense codes, the rest is counted by the sparse route's incidence lists) -- 32-byte LDS slots, two 1 KiB DMA
+# pieces per wave and stage, four two-plane steps, a 24 KiB ring.
+if PLANES == 8:
+    assert PERSIST and not INLOOP
+SEGS, STEPS = (3, 6) if PLANES == 12 else (2, 4) if PLANES == 8 else (5, (PLANES + 1) // 2)   # 16-byte units per LDS slot; 2-plane steps per stage
 HALF_LAST = PLANES == 15                                            # the last step's odd plane is zero in the operand: its instruction is left out
 STAGE_BYTES = 256 * SEGS * 16  # 12288 (20480 with the padded 16-plane slots)
 ROW = 16 * SEGS * 16          # byte distance between the lane's rows / columns in LDS: 768 (1280)
@@ -174,8 +180,8 @@ def wrap_slot(reg):
     e("8:")
 
 def issue_saddr():
-    """DMA of one stage from the wave's running base s[48:49] (three 1 KiB pieces), then advance the base by a stage"""
-    for q in range(3):
+    """DMA of one stage from the wave's running base s[48:49] (SEGS 1 KiB pieces), then advance the base by a stage"""
+    for q in range(SEGS):
         e("s_add_u32 m0, %s, %d" % (S_M0, q * 1024))
         e("s_add_u32 s50, s48, %d" % (q * 1024))
         e("s_addc_u32 s51, s49, 0")
@@ -184,7 +190,7 @@ def issue_saddr():
     e("s_addc_u32 s49, s49, 0")
 
 def gen_persistent():
-    e("// generated by tools/gen_k2_asm.py (K2ASM_PERSIST=1) -- do not edit")
+    e("// generated by tools/gen_k2_asm.py (K2ASM_PERSIST=1%s) -- do not edit" % ("" if PLANES == 12 else " K2ASM_PLANES=%d" % PLANES))
     e("s_mov_b32 s47, m0")
     if PRIO:
         e("s_setprio %d" % PRIO)
@@ -194,7 +200,7 @@ def gen_persistent():
     for r in range(8):
         for c2 in range(4):
             e("v_mov_b32 %s, 0" % mis(r, c2))
-    e("s_mul_i32 %s, %%[wv], 3072" % S_TMP)
+    e("s_mul_i32 %s, %%[wv], %d" % (S_TMP, SEGS * 1024))
     e("s_add_u32 s46, %[lb], " + S_TMP)                 # ring + this wave's part of a stage
     e("s_mov_b32 %s, %%[sp]" % S_SLOT)                  # ring slot (byte offset) of the stage being computed
     e("s_add_u32 %s, %%[sp], %d" % (S_ISSUE_SLOT, 2 * STAGE_BYTES))
@@ -233,7 +239,7 @@ def gen_persistent():
     e("s_waitcnt vmcnt(0)")
     e("s_branch 4f")
     e("21:")
-    e("s_waitcnt vmcnt(3)")
+    e("s_waitcnt vmcnt(%d)" % SEGS)
     e("4:")
     if QTIMING:
         e("s_memtime s[66:67]")
@@ -272,7 +278,7 @@ def gen_persistent():
     cur = 0
     for k in range(STEPS):
         cur = step(k, first=(k == 0), last=(k == STEPS - 1), cur=cur)
-    assert cur == 0
+    assert cur == 0 or PLANES == 8   # (every stage preloads buffers 0 and 1 afresh: the loop body is emitted once and starts at buffer 0)
     e("s_add_u32 %s, %s, %d" % (S_SLOT, S_SLOT, STAGE_BYTES))
     e("s_cmp_lt_u32 %s, %d" % (S_SLOT, 3 * STAGE_BYTES))
     e("s_cselect_b32 %s, %s, 0" % (S_SLOT, S_SLOT))
