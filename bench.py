@@ -513,7 +513,9 @@ def main():
         lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
         # 12 / 16 code planes, symmetric mode: the hand-scheduled kernels do all but the diagonal / border tiles
         f64s = "true" if out_elem == 8 else "false"
-        if world == 1 and plane_bits == 12:
+        if world == 1 and plane_bits == 8 and 32 < n_hash < 512:   # the dense half of the heavy / rare split: <float64, planes, one tile per workgroup>
+            k2_name = "k_mh_compare_p12<%s, 8, true>" % f64s
+        elif world == 1 and plane_bits == 12:
             k2_name = "k_mh_compare_a12<%s>" % f64s
         elif world == 1 and plane_bits in (14, 15, 16):      # <float64 output, code bits>: 14 / 15 skip the top planes' step / half step
             k2_name = "k_mh_compare_a16<%s, %d>" % (f64s, plane_bits)
@@ -627,8 +629,13 @@ def main():
             dph = phase_means(devs)
             droof = k2_roofline(dph["k2_ms"], state["bits"])
             droof["step_frac"] = step_bytes / (ddt / dsteps) / 1e9 / HBM_PEAK_GBS
+            dlast = devs[-1]
             line["direct"] = {"ms_per_step": ddt / dsteps * 1e3, "value": pairs_mh / (ddt / dsteps), "unit": "pairs/s", "steps": dsteps,
                               "phases_ms": dph, "roofline": droof,
+                              "split": {"taken": dlast.get("split", False), "rare_incidences": dlast.get("rare_pairs", 0), "plane_bits": dlast["plane_bits"],
+                                        "plane_bits_without": dlast.get("plane_bits_without", 0),
+                                        "note": "heavy / rare split of the column dictionaries: the compare on 8 planes of dense codes for each column's 254 most "
+                                                "frequent values + the rare values' incidences added from lists (k2_ms = compare + fix-up; the list kernels run beside it)"},
                               "note": "DYNAALIGN_MH_NO_DEDUP=1: every row goes through K1 / K1b / K2"}
             state["bits"] = route["plane_bits"]
     def same_as_single_gpu(compute_ref):

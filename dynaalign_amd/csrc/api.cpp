@@ -877,8 +877,8 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       // beside the first band on the side stream: the table's diagonal / border tiles and the copy lists, both on the caller's stream
       DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
       if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, stream, bits)) != DA_OK) return rc;
-      if (hy.take && (rc = hy_lists(stream)) != DA_OK) return rc;
       if ((rc = launch_expand_stream_lists(p.uidx, n, U, lists.p, stream)) != DA_OK) return rc;
+      if (hy.take && (rc = hy_lists(stream)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(pe[3 * C], stream));
       if (alt) { DA_HIP_TRY(hipStreamWaitEvent(pr->alt[0], pe[3 * C], 0)); DA_HIP_TRY(hipStreamWaitEvent(pr->alt[1], pe[3 * C], 0)); }
       for (size_t c = 0; c < C; ++c) {

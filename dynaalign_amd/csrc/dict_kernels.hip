@@ -200,9 +200,17 @@ __global__ __launch_bounds__(1024) void k_hy_split(const uint16_t *__restrict__ 
   uint16_t *outD = idsD + (int64_t)blockIdx.x * ld_ids, *outS = idsS + (int64_t)blockIdx.x * ld_ids;
   for (int c = tid; c < max_ids; c += 1024) hy_hist[c] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const uint32_t c = ids[i];
-    if (c != 0xFFFFu) atomicAdd(&hy_hist[c], 1u);
+  // (eight codes per 16-byte load: the rows are 128-byte aligned and padded to a multiple of 64 codes -- both passes over the column are latency-bound otherwise)
+  const uint4 *ids8 = reinterpret_cast<const uint4 *>(ids);
+  const int n8 = (n + 7) / 8;
+  for (int q = tid; q < n8; q += 1024) {
+    const uint4 v = ids8[q];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t c = (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+      if (q * 8 + u < n && c != 0xFFFFu) atomicAdd(&hy_hist[c], 1u);
+    }
   }
   __syncthreads();
   auto count_ge = [&](uint32_t t) -> uint32_t {      // how many codes occur at least t times (uniform result)
@@ -262,11 +270,21 @@ __global__ __launch_bounds__(1024) void k_hy_split(const uint16_t *__restrict__ 
   }
   if (lane == 0) { atomicAdd(&stats[0], e); atomicMax(&stats[1], mx); atomicAdd(&stats[2], e_all); atomicMax(&stats[3], mx_all); }
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const uint32_t c = ids[i];
-    const uint32_t r = c == 0xFFFFu ? 0xFFFFu : hy_hist[c];
-    outD[i] = (uint16_t)r;
-    outS[i] = (uint16_t)((c != 0xFFFFu && r == 0xFFFFu) ? c : 0xFFFFu);
+  uint4 *outD8 = reinterpret_cast<uint4 *>(outD), *outS8 = reinterpret_cast<uint4 *>(outS);
+  for (int q = tid; q < n8; q += 1024) {                     // (codes past n inside the last 16 bytes: written as 0xFFFF, never read)
+    const uint4 v = ids8[q];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t d[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t c = (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+      const bool live = q * 8 + u < n && c != 0xFFFFu;
+      const uint32_t r = live ? hy_hist[c] : 0xFFFFu;
+      d[u >> 1] |= r << (16 * (u & 1));
+      sp[u >> 1] |= ((live && r == 0xFFFFu) ? c : 0xFFFFu) << (16 * (u & 1));
+    }
+    outD8[q] = make_uint4(d[0], d[1], d[2], d[3]);
+    outS8[q] = make_uint4(sp[0], sp[1], sp[2], sp[3]);
   }
 }
 

@@ -1513,7 +1513,16 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
   const bool a8 = symmetric && plane_bits == 8 && !config().k2_no_asm && (ld & 1) == 0 && n_hash > K2_GROUP &&
                   (kind != DA_OUT_F64 || n_hash < K2_P12_TABLE) && per_xcd < 0x7fffffffLL &&
                   (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;
-  if (a8) {
+  if (a8 && config().k2_persist) {            // DYNAALIGN_K2_PERSIST=1 (experiment): four resident workgroups per CU walk the tiles
+    int wg_per_xcd = 4 * 32;
+    if (config().k2_wg_per_cu > 0) wg_per_xcd = config().k2_wg_per_cu * 32;
+    if ((int64_t)wg_per_xcd > per_xcd) wg_per_xcd = (int)(per_xcd > 0 ? per_xcd : 1);
+    const dim3 pgrid((unsigned)(8 * wg_per_xcd));
+    if (kind == DA_OUT_F64)
+      hipLaunchKernelGGL((k_mh_compare_p12<true, 8, false>), pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd, (int64_t)0);
+    else
+      hipLaunchKernelGGL((k_mh_compare_p12<false, 8, false>), pgrid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, wg_per_xcd, (int64_t)0);
+  } else if (a8) {
     if (kind == DA_OUT_F64)
       hipLaunchKernelGGL((k_mh_compare_p12<true, 8, true>), grid, block, 0, stream, d_planes, n, n_hash, d_out, ld, ntiles, per_xcd, (int)per_xcd, (int64_t)0);
     else
@@ -2871,7 +2880,7 @@ int launch_mh_sparse(const uint16_t *d_idsT, int64_t ld_ids, int64_t n, int n_ha
 
 // ---- heavy / rare split: the rare values' incidences ADDED to a finished dense result (dict_kernels.hip k_hy_split) ------------------------
 // Tiles with more than HY_SMALL entries -- one workgroup per (tile row, column phase): the entries are counted into a 128 x 128 LDS image (atomics), then every entry's
-// thread swaps its cell for zero: whoever gets a non-zero count m owns the pair and applies it -- element (i, j) and its mirror image:
+// thread clears its cell: whoever gets a non-zero count m back owns the pair and applies it -- element (i, j) and its mirror image:
 //   float64:  the dense kernel stored count / n_hash (correctly rounded): count = (int)(v * n_hash + 0.5) exactly (|v n_hash - count| < 2^-36),
 //             new value (count + m) / n_hash -- the same IEEE division as every other kernel (src/minHash.cpp:174);
 //   uint16:   count += m.
@@ -2918,7 +2927,7 @@ __global__ __launch_bounds__(256) void k_hy_fixup_small(const uint32_t *__restri
 template <bool F64>
 __global__ __launch_bounds__(256) void k_hy_fixup(const uint32_t *__restrict__ start, const uint16_t *__restrict__ entries, int n_hash, void *__restrict__ out_v,
                                                   int64_t ld, int T, int tile_row_begin) {
-  __shared__ uint32_t img[128 * 128];
+  __shared__ uint32_t img[128 * 128 / 2];          // two uint16 counts per word (a count is <= n_hash <= 2047: no carry); 32 KiB fits beside the row expansion
   const int tid = threadIdx.x, ti = tile_row_begin + (int)blockIdx.x;
   bool zeroed = false;
   for (int tj = ti + (int)blockIdx.y; tj < T; tj += (int)gridDim.y) {
@@ -2926,14 +2935,18 @@ __global__ __launch_bounds__(256) void k_hy_fixup(const uint32_t *__restrict__ s
     const uint32_t e0 = start[t], e1 = start[t + 1];
     if (e1 - e0 <= HY_SMALL) continue;                               // (uniform; those tiles: k_hy_fixup_small)
     if (!zeroed) {
-      for (int w = tid; w < 128 * 128; w += 256) img[w] = 0u;
+      for (int w = tid; w < 128 * 128 / 2; w += 256) img[w] = 0u;
       __syncthreads();
       zeroed = true;
     }
-    for (uint32_t e = e0 + tid; e < e1; e += 256) atomicAdd(&img[entries[e]], 1u);     // entry = (row & 127) << 7 | (column & 127)
+    for (uint32_t e = e0 + tid; e < e1; e += 256) {                  // entry = (row & 127) << 7 | (column & 127)
+      const uint32_t v = entries[e];
+      atomicAdd(&img[v >> 1], 1u << (16 * (v & 1u)));
+    }
     __syncthreads();
     for (uint32_t e = e0 + tid; e < e1; e += 256) {
-      const uint32_t v = entries[e], m = atomicExch(&img[v], 0u);
+      const uint32_t v = entries[e], sh = 16 * (v & 1u);
+      const uint32_t m = (atomicAnd(&img[v >> 1], ~(0xffffu << sh)) >> sh) & 0xffffu;     // the first thread to clear the cell owns the pair
       if (!m) continue;
       hy_apply<F64>(out_v, ld, n_hash, (int64_t)ti * 128 + (v >> 7), (int64_t)tj * 128 + (v & 127u), m);
     }
@@ -2946,7 +2959,11 @@ int launch_mh_sparse_fixup(const uint32_t *d_scratch, const uint16_t *d_entries,
   const SparseScratch w = sparse_scratch(const_cast<uint32_t *>(d_scratch), n, n_hash, max_ids, ld_ids);
   if (tile_row_end > w.T) tile_row_end = w.T;
   if (tile_row_end <= tile_row_begin) return DA_OK;
-  const dim3 grid((unsigned)(tile_row_end - tile_row_begin), 4);
+  // column phases per tile row: enough workgroups to fill the chip even when a call covers one band of the table (pipelined duplicate route) -- a workgroup
+  // walks its tiles one after the other, three dependent global accesses each
+  const int64_t rows = tile_row_end - tile_row_begin;
+  const unsigned phases = (unsigned)std::max<int64_t>(4, std::min<int64_t>(ceil_div(w.T, 4), ceil_div(4096, rows)));
+  const dim3 grid((unsigned)rows, phases);
   if (kind == DA_OUT_F64) {
     hipLaunchKernelGGL(k_hy_fixup_small<true>, grid, dim3(256), 0, stream, w.start, d_entries, n_hash, d_out, ld, w.T, (int)tile_row_begin);
     hipLaunchKernelGGL(k_hy_fixup<true>, grid, dim3(256), 0, stream, w.start, d_entries, n_hash, d_out, ld, w.T, (int)tile_row_begin);

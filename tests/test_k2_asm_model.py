@@ -43,6 +43,29 @@ def test_committed_persistent_include_is_the_generators_output(tmp_path):
     assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", "k2_loop_p12p.inc")).read()
 
 
+@pytest.mark.parametrize("inc", ["k2_loop_p8p.inc", "k2_loop_p8.inc"])
+@pytest.mark.parametrize("ntiles,ns,tx,ty", [(1, 16, 0, 0), (2, 16, 5, 11), (3, 16, 15, 15), (4, 2, 7, 8), (3, 3, 1, 2), (5, 5, 9, 4), (2, 17, 3, 3)])
+def test_8_plane_persistent_blocks(inc, ntiles, ns, tx, ty):
+    """the dense half of the heavy / rare split (round 4): the persistent block on EIGHT code planes -- 32-byte LDS slots, two DMA pieces per
+    wave and stage, four two-plane steps, a 24 KiB ring; k2_loop_p8p.inc is the band kernel's block, k2_loop_p8.inc the same with the stage
+    loop at wave priority 2 (one tile per workgroup: called with flags first / no next only, but the tile-sequence model holds for it too)"""
+    import sim_k2_asm
+    path = os.path.join(ROOT, "dynaalign_amd", "csrc", inc)
+    issued, bad = sim_k2_asm.run_persistent(tx, ty, seed=ntiles * 100 + ns, ntiles=ntiles, ns=ns, inc=path, planes=8, slot_bytes=32, ring=3)
+    assert issued == ntiles * ns and bad == 0
+
+
+@pytest.mark.parametrize("inc,prio", [("k2_loop_p8p.inc", None), ("k2_loop_p8.inc", "2")])
+def test_committed_8_plane_includes_are_the_generators_output(tmp_path, inc, prio):
+    out = tmp_path / "k2_8.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("K2ASM_")}
+    env.update({"K2ASM_PERSIST": "1", "K2ASM_PLANES": "8"})
+    if prio:
+        env["K2ASM_PRIO"] = prio
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_k2_asm.py"), str(out)], env=env, stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "dynaalign_amd", "csrc", inc)).read()
+
+
 @pytest.mark.parametrize("ns,tx,ty", [(16, 0, 0), (1, 5, 11), (2, 15, 15), (3, 7, 8), (5, 9, 4)])
 def test_16_plane_block(ns, tx, ty):
     """the block of k_mh_compare_a16: padded 80-byte slots, ring of two stages, five DMA pieces per wave and stage"""
