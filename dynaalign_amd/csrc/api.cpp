@@ -545,7 +545,7 @@ struct SparseHint { bool take = false; int max_ids = 0; uint64_t pairs = 0, max_
 // *bits_out = 8) and leaves the codes of the rare repeated values in the workspace (sparse_codes): the caller runs launch_mh_sparse_lists on them
 // and, after the dense compare, launch_mh_sparse_fixup.
 constexpr int HY_KEEP = 254;
-struct HybridHint { bool take = false; int max_ids = 0, bits_before = 0; uint64_t pairs = 0, max_mult = 0; const uint16_t *sparse_codes = nullptr; int64_t ld_ids = 0; };
+struct HybridHint { int only_from_bits = 12; bool take = false; int max_ids = 0, bits_before = 0; uint64_t pairs = 0, max_mult = 0; const uint16_t *sparse_codes = nullptr; int64_t ld_ids = 0; };
 // min_bits: 0 = as few code planes as the data needs, 12 / 16 = at least that many, 32 = raw planes
 static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_hash, int min_bits, void *d_work,
                         size_t work_bytes, uint32_t *d_planes, int *bits_out, hipStream_t stream, SparseHint *sparse = nullptr,
@@ -566,7 +566,7 @@ static int build_planes(const uint32_t *d_sig, int64_t ld_sig, int64_t n, int n_
     if (da::config().mh_hybrid_min_n >= 0) hy_min_n = da::config().mh_hybrid_min_n;   // DYNAALIGN_MH_HYBRID_MIN_N (tests lower it)
     const bool sparse_ok = sparse && status[0] == 0 && status[1] >= 1 && status[1] <= 32768 && min_bits == 0 && n >= 2048 && n_hash + 1 <= 2048 &&
                            !da::config().mh_no_sparse;
-    const bool hybrid_ok = hybrid && status[0] == 0 && bits_data >= 12 && bits_data <= 16 && min_bits == 0 && status[1] <= 32768 && n >= hy_min_n && n <= 131072 &&
+    const bool hybrid_ok = hybrid && status[0] == 0 && bits_data >= hybrid->only_from_bits && bits_data <= 16 && min_bits == 0 && status[1] <= 32768 && n >= hy_min_n && n <= 131072 &&
                            n_hash > 32 && n_hash + 1 <= 2048 && !da::config().mh_no_hybrid && !da::config().k2_no_asm;
     if (sparse_ok || hybrid_ok) {
       // how many (pair, hash function) incidences match, and how large is the largest class -- over all repeated values (sparse route) and over the values
@@ -763,10 +763,11 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
   // the sparse route is only worth asking about when the input has few duplicates (clustered inputs have large classes: the dense kernels win)
   const bool ask_sparse = !take && U * 10 >= n * 9;
   // the heavy / rare split (8 dense planes + incidence lists for the rare values): the direct route; the duplicate route's table compare on request
+  // (duplicate route: when the table's dictionaries need more than 12 planes -- there is no banded kernel for those, so the split is what lets the
+  // route pipeline at all; with 12 planes the pipelined route gains 0.2 ms of 16.8 from it at 100k, profiles/r04_l_*: on request only)
   HybridHint hy;
-  const bool ask_hybrid = !take || da::config().mh_hybrid_dedup;
-  if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream, ask_sparse ? &sp : nullptr,
-                         ask_hybrid ? &hy : nullptr)) != DA_OK) return rc;
+  if (take && !da::config().mh_hybrid_dedup) hy.only_from_bits = 13;
+  if ((rc = build_planes(sig.as<uint32_t>(), lds, m, n_hash, 0, pwork.p, wb, planes.as<uint32_t>(), &bits, stream, ask_sparse ? &sp : nullptr, &hy)) != DA_OK) return rc;
   DevBuf hy_scratch, hy_entries32, hy_entries;
   if (hy.take) {
     // the split is an optimisation: when the lists' scratch does not fit, the planes are rebuilt with all the code bits

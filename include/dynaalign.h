@@ -248,7 +248,8 @@ int da_dev_mh_compare(const uint32_t *d_planes, int plane_bits, int64_t n, int n
  *                                 (tiles), time some expansion launch was running, diagonal / border tiles} -- the middle three overlap;
  *                                 da_mh_last_route_chunks gives the number of chunks and of expansion launches.
  * All forms write the same bits.
- * Heavy / rare split (round 4; the direct route, and the duplicate route's table compare with DYNAALIGN_MH_HYBRID_DEDUP=1): when the column
+ * Heavy / rare split (round 4; the direct route; the duplicate route's table compare when its dictionaries need more than 12 planes -- the banded kernel of the
+ * pipelined forms exists for 12 and 8 planes -- or with DYNAALIGN_MH_HYBRID_DEDUP=1): when the column
  * dictionaries need 12 - 16 code planes but nearly all matching incidences sit on each column's 254 most frequent values (clustered data: 7e6 of
  * 2.2e10 on the h3n2-like 100k set), the bit-sliced compare runs on EIGHT planes of dense codes for those values -- every other value reads as
  * "never equal" -- and the incidences of the remaining repeated values are enumerated by the sparse route's list kernels and added to the result

@@ -118,6 +118,21 @@ def test_every_signature_row_and_2000_count_rows_against_the_oracle(da, h3n2, bu
         route = device.mh_last_route()
         assert route["dedup"] and route["expansion"] == name
         _same_bits(out, ref)
+    # the one call without the duplicate collapse: the heavy / rare split (8 dense planes + 7.2e6 incidences from lists; round 4) and the full-width
+    # compare; and the split inside the duplicate route (opt-in) -- whole matrix each
+    for switches, dedup, split in (({"DYNAALIGN_MH_NO_DEDUP": "1"}, False, True), ({"DYNAALIGN_MH_NO_DEDUP": "1", "DYNAALIGN_MH_NO_HYBRID": "1"}, False, False),
+                                   ({"DYNAALIGN_MH_HYBRID_DEDUP": "1"}, True, True)):
+        out.fill_(-1.0)
+        os.environ.update(switches)
+        try:
+            device.similarity_mh(ds, K, N_HASH, seeds, out=out)
+        finally:
+            for key in switches:
+                del os.environ[key]
+        route = device.mh_last_route()
+        assert route["dedup"] == dedup and route["split"] == split and route["plane_bits"] == (8 if split else 12), route
+        assert not split or (route["rare_pairs"] > 0 and route["plane_bits_without"] == 12)
+        _same_bits(out, ref)
 
 
 def test_row_expansion_with_more_than_49152_unique_strings(da, h3n2, bufs):
@@ -147,9 +162,14 @@ def test_row_expansion_with_more_than_49152_unique_strings(da, h3n2, bufs):
             finally:
                 del os.environ["DYNAALIGN_MH_EXPAND"]
             route = device.mh_last_route()
-            if form == "rowspipe" and route["plane_bits"] != 12:          # (the added random peptides can push the dictionary past 12 code planes:
-                name = "rows"                                              #  the banded compare is the 12-plane kernel, so no pipeline then)
+            # (the added random peptides push the table's dictionaries past 12 code planes: the banded compare exists for 12 and 8 planes, so the route
+            #  pipelines when the heavy / rare split brings the compare down to 8 planes -- round 4 -- and runs one kernel after the other otherwise)
+            if form == "rowspipe" and route["plane_bits"] not in (8, 12):
+                name = "rows"
             assert route["dedup"] and route["expansion"] == name and route["unique"] == unique
+            assert route["split"] == (route["plane_bits"] == 8)
+            if route["split"]:
+                assert route["plane_bits_without"] > 12 and route["rare_pairs"] > 0
             if form != "tiles":
                 _same_bits(out, ref)
         sig = O.signatures(seqs, K, n_hash, seeds) if n_hash == 640 else None
