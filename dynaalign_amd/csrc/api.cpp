@@ -930,7 +930,8 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
     return DA_OK;
   }
   if ((rc = ftab.alloc(expand_rows_workspace_bytes(n, U, DA_OUT_F64, false, n_hash, 0))) != DA_OK) return rc;
-  if (form != "tiles" && !ub.empty() && may_pipe) do {
+  // (the pipelined tile form leaves only diagonal / border tiles to launch_expand_unique: the output must qualify for the streaming passes)
+  if (form != "tiles" && !ub.empty() && may_pipe && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) do {
     // PIPELINED form.  The table is compared band by band (1024 unique rows each, in order) by the persistent kernel on
     // a side stream with only `wg` workgroups per CU, so the rest of every CU stays free; the output row bands whose strings are all
     // numbered below the finished table rows are gathered (on `stream`) and expanded (on two alternating streams: chunk c + 1 fills

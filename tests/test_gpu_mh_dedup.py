@@ -320,11 +320,11 @@ def test_row_expansion_needs_an_even_leading_dimension(da, small_n_route):
     buf = torch.full((n, n + 1), -1.0, dtype=torch.float64, device="cuda")
     device.similarity_mh(ds, 4, 64, seeds, out=buf[:, :n])
     route = device.mh_last_route()
-    assert route["dedup"] and route["expansion"] != "rows"
+    assert route["dedup"] and not route["expansion"].startswith("rows")
     assert same(buf[:, :n].cpu().numpy(), oracle(seqs, 4, 64)) and bool((buf[:, n] == -1.0).all())
     buf2 = torch.full((n, n + 2), -1.0, dtype=torch.float64, device="cuda")
     device.similarity_mh(ds, 4, 64, seeds, out=buf2[:, :n])
-    assert device.mh_last_route()["expansion"] == "rows"
+    assert device.mh_last_route()["expansion"] in ("rows", "rows, pipelined")     # (8-plane dictionaries: the banded compare exists since round 4)
     assert same(buf2[:, :n].cpu().numpy(), oracle(seqs, 4, 64)) and bool((buf2[:, n:] == -1.0).all())
 
 
