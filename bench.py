@@ -513,7 +513,7 @@ def main():
         lane_ops = tiles * 128 * 128 * 16 * plane_bits    # one v_bitop3 per pair and bit plane (16 groups x 8..32 planes)
         # 12 / 16 code planes, symmetric mode: the hand-scheduled kernels do all but the diagonal / border tiles
         f64s = "true" if out_elem == 8 else "false"
-        if world == 1 and plane_bits == 8 and 32 < n_hash < 512:   # the dense half of the heavy / rare split: <float64, planes, one tile per workgroup>
+        if world == 1 and plane_bits == 8 and 32 < n_hash < 2048:   # the dense half of the heavy / rare split: <float64, planes, one tile per workgroup>
             k2_name = "k_mh_compare_p12<%s, 8, true>" % f64s
         elif world == 1 and plane_bits == 12:
             k2_name = "k_mh_compare_a12<%s>" % f64s

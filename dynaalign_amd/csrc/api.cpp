@@ -871,21 +871,25 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       std::vector<int64_t> cuts{0};
       while (cuts.back() < KB) cuts.push_back(std::min(KB, cuts.back() + (cuts.size() == 1 ? head : step)));
       const size_t C = cuts.size() - 1;
-      PipeRes *pr = pipe_acquire(3 * C + 1);
+      PipeRes *pr = pipe_acquire(3 * C + 2);
       if (!pr) break;   // no side stream / events to be had: the one-stream form below needs none
       struct PipeGuard { PipeRes *r; ~PipeGuard() { (void)hipStreamSynchronize(r->side); (void)hipStreamSynchronize(r->alt[0]); (void)hipStreamSynchronize(r->alt[1]); pipe_release(r); } } pguard{pr};
       hipEvent_t *pe = pr->ev.data();                                // per chunk: table rows done, rows begin / end; [3 C]: lists done
       // beside the first band on the side stream: the table's diagonal / border tiles and the copy lists, both on the caller's stream
       DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
+      if (hy.take) {     // the rare values' lists on the first expansion stream (idle until the first band is done): their codes were complete before build_planes' read-back
+        const hipStream_t ls = alt ? pr->alt[0] : stream;
+        if ((rc = hy_lists(ls)) != DA_OK) return rc;
+        DA_HIP_TRY(hipEventRecord(pe[3 * C + 1], ls));
+      }
       if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, stream, bits)) != DA_OK) return rc;
       if ((rc = launch_expand_stream_lists(p.uidx, n, U, lists.p, stream)) != DA_OK) return rc;
-      if (hy.take && (rc = hy_lists(stream)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(pe[3 * C], stream));
       if (alt) { DA_HIP_TRY(hipStreamWaitEvent(pr->alt[0], pe[3 * C], 0)); DA_HIP_TRY(hipStreamWaitEvent(pr->alt[1], pe[3 * C], 0)); }
       for (size_t c = 0; c < C; ++c) {
         if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, cuts[c], cuts[c + 1], c == 0 ? 4 : wg, pr->side, bits)) != DA_OK) return rc;
         if (hy.take) {     // the rare values' incidences of these tile rows (direct + mirrored elements), once the edge tiles and the lists are there
-          if (c == 0) DA_HIP_TRY(hipStreamWaitEvent(pr->side, pe[3 * C], 0));
+          if (c == 0) { DA_HIP_TRY(hipStreamWaitEvent(pr->side, pe[3 * C], 0)); DA_HIP_TRY(hipStreamWaitEvent(pr->side, pe[3 * C + 1], 0)); }
           if ((rc = hy_fixup(DA_OUT_COMPACT, dtab.p, ld_d, cuts[c] * 8, cuts[c + 1] * 8, pr->side)) != DA_OK) return rc;
         }
         DA_HIP_TRY(hipEventRecord(pe[3 * c], pr->side));

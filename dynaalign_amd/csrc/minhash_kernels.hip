@@ -787,7 +787,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_s16(const uint32_t
 #ifdef K2_DYNAMIC   // experiment: tile ids handed out by a per-XCD atomic counter (a sliding window like the hardware dispatcher's)
 __device__ unsigned int g_k2_next[8];
 #endif
-constexpr int K2_P12_TABLE = 512;
+constexpr int K2_P12_TABLE = 512, K2_P8_TABLE = 2048;
 // PL = 12, or 8: the dense half of the heavy / rare split (round 4; dict_kernels.hip k_hy_split): 32-byte slots, a 24 KiB ring, four two-plane
 // steps per stage -- k2_loop_p8p.inc (band kernel: no wave priority) / k2_loop_p8.inc (ONE = one tile per workgroup, the grid of k_mh_compare_a12:
 // the launcher passes wg_per_xcd = per_xcd; priority 2 inside the stage loop like k_mh_compare_a12's block).
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(K2_THREADS, 4) void k_mh_compare_p12(const uint32_t
   static_assert(PL == 12 || PL == 8, "generated blocks exist for 12 and 8 planes");
   constexpr int SEGS = PL / 4, STAGE_UNITS = 2 * K2_TILE * SEGS;
   __shared__ __attribute__((aligned(16))) uint4 lds_ab[3 * STAGE_UNITS];   // 36 KiB ring (24 KiB at PL = 8)
-  __shared__ double ratio_tab[F64 ? K2_P12_TABLE : 1];
+  __shared__ double ratio_tab[F64 ? (PL == 8 ? K2_P8_TABLE : K2_P12_TABLE) : 1];   // (PL = 8: the ring is 12 KiB smaller, the table may be 12 KiB larger)
   const int T = (int)((n + K2_TILE - 1) / K2_TILE);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   // tile ids fit 31 bits (the launcher checks): 32-bit scalars, so that loop control stays on the scalar unit -- nothing
@@ -1509,9 +1509,9 @@ int launch_mh_compare(const uint32_t *d_planes, int64_t n, int n_hash,
                    (kind != DA_OUT_F64 || (int64_t)n_hash + 1 <= K2_A16_TABLE_MAX) &&
                    (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;
   // symmetric 8-plane compares (the dense half of the heavy / rare split): the persistent kernel's 8-plane block, one tile per workgroup
-  // (wg_per_xcd = per_xcd: the grid and tile order of k_mh_compare_a12); float64 needs its 4 KiB table, two stages at least
+  // (wg_per_xcd = per_xcd: the grid and tile order of k_mh_compare_a12); float64 needs its table (16 KiB beside the 24 KiB ring: n_hash <= 2047), two stages at least
   const bool a8 = symmetric && plane_bits == 8 && !config().k2_no_asm && (ld & 1) == 0 && n_hash > K2_GROUP &&
-                  (kind != DA_OUT_F64 || n_hash < K2_P12_TABLE) && per_xcd < 0x7fffffffLL &&
+                  (kind != DA_OUT_F64 || n_hash < K2_P8_TABLE) && per_xcd < 0x7fffffffLL &&
                   (reinterpret_cast<uintptr_t>(d_out) & (kind == DA_OUT_F64 ? 15 : 3)) == 0;
   if (a8 && config().k2_persist) {            // DYNAALIGN_K2_PERSIST=1 (experiment): four resident workgroups per CU walk the tiles
     int wg_per_xcd = 4 * 32;
