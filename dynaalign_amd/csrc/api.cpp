@@ -877,14 +877,13 @@ static int mh_full_symmetric(const uint8_t *d_res, const int64_t *d_off, int64_t
       hipEvent_t *pe = pr->ev.data();                                // per chunk: table rows done, rows begin / end; [3 C]: lists done
       // beside the first band on the side stream: the table's diagonal / border tiles and the copy lists, both on the caller's stream
       DA_HIP_TRY(hipStreamWaitEvent(pr->side, ev[2], 0));
-      if (hy.take) {     // the rare values' lists on the first expansion stream (idle until the first band is done): their codes were complete before build_planes' read-back
-        const hipStream_t ls = alt ? pr->alt[0] : stream;
-        if ((rc = hy_lists(ls)) != DA_OK) return rc;
-        DA_HIP_TRY(hipEventRecord(pe[3 * C + 1], ls));
-      }
       if ((rc = launch_mh_compare_edges_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, stream, bits)) != DA_OK) return rc;
       if ((rc = launch_expand_stream_lists(p.uidx, n, U, lists.p, stream)) != DA_OK) return rc;
       DA_HIP_TRY(hipEventRecord(pe[3 * C], stream));
+      if (hy.take) {     // the rare values' lists behind them on the caller's stream (on the idle expansion stream instead: 17.3 vs 16.6 ms, round 4)
+        if ((rc = hy_lists(stream)) != DA_OK) return rc;
+        DA_HIP_TRY(hipEventRecord(pe[3 * C + 1], stream));
+      }
       if (alt) { DA_HIP_TRY(hipStreamWaitEvent(pr->alt[0], pe[3 * C], 0)); DA_HIP_TRY(hipStreamWaitEvent(pr->alt[1], pe[3 * C], 0)); }
       for (size_t c = 0; c < C; ++c) {
         if ((rc = launch_mh_compare_bands_u16(planes.as<uint32_t>(), U, n_hash, dtab.as<uint16_t>(), ld_d, cuts[c], cuts[c + 1], c == 0 ? 4 : wg, pr->side, bits)) != DA_OK) return rc;

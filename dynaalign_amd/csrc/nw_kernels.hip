@@ -150,14 +150,31 @@ template <int NMAX> struct CKBits {
 };
 
 //   VM[c] : combined best'[r-1][c] (priority cleared)     XP[c] : Ix'[r-1][c]*2^15 | priority 1 | payload of cell (r-1,c)
-template <int NMAX, bool FIRST>
+// PACKB: sequence2's table offsets (<= 92 bytes each) four to a register in boff[0 .. NMAX / 4) -- one v_bfe_u32 more per cell, off the dependent chain
+// (the row is bound by that chain, profiles/r04_c_*), fifteen VGPRs less: what lets the prefix-sharing kernel run five waves per SIMD
+template <int NMAX, bool FIRST, bool PACKB = false>
 __device__ __forceinline__ void nw_row_ck(int32_t (&VM)[NMAX], int32_t (&XP)[NMAX], const uint32_t (&boff)[NMAX],
                                           const char *tab_row, int32_t vm_diag0, int32_t vm_left0, int32_t yp_left0,
                                           int32_t kx, int32_t ky, int32_t ixf_first, int32_t pay_mask, int32_t pri_clear) {
   int32_t vmd = vm_diag0, vml = vm_left0, ypl = yp_left0;
 #pragma unroll
   for (int c = 0; c < NMAX; ++c) {
-    const int32_t e = *reinterpret_cast<const int32_t *>(tab_row + boff[c]);
+    int32_t e;
+    if constexpr (PACKB) {
+      // byte (c & 3) of the packed offsets + the row's table address in ONE SDWA add, as an asm statement: written in C++ the unpacking is loop-invariant
+      // and hoisted out of the row loop -- twenty registers again
+      typedef __attribute__((address_space(3))) const char lds_char_t;
+      typedef __attribute__((address_space(3))) const int32_t lds_i32_t;
+      const uint32_t base = (uint32_t)(uintptr_t)(lds_char_t *)tab_row;
+      uint32_t addr;
+      if ((c & 3) == 0) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(addr) : "v"(boff[c >> 2]), "v"(base));
+      else if ((c & 3) == 1) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(addr) : "v"(boff[c >> 2]), "v"(base));
+      else if ((c & 3) == 2) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(addr) : "v"(boff[c >> 2]), "v"(base));
+      else asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(addr) : "v"(boff[c >> 2]), "v"(base));
+      e = *(lds_i32_t *)(uintptr_t)addr;
+    } else {
+      e = *reinterpret_cast<const int32_t *>(tab_row + boff[c]);
+    }
     // up: max(M-goe, Ix-ge), priority 1, payload of the cell above            (reference :255-257, :273-275)
     const int32_t ixf = FIRST ? ixf_first : max(VM[c] + kx, XP[c]);
     // left: max(M-goe, Iy-ge), priority 0, payload of the cell to the left             (:260-262, :276-278)
@@ -196,7 +213,7 @@ template <int NMAX> constexpr bool nw_has_asm_rows() { return false; }
 // common prefix of the strings at sorted positions pos - 1 and pos.  Same cells, same arithmetic: bit-identical; 30 % fewer DP rows on
 // the h3n2-like headline set (mean shared prefix of sorted neighbours 8.5 of 20), 12 % on uniform peptides.
 template <int NMAX, bool CK, bool ORD, bool ASM = false, bool PFX = false>
-__global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short(   // <= 24 residues: keep 4 waves per SIMD (128 VGPRs)
+__global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? (CK && ORD && !ASM ? 5 : 4) : 1)) void k_nw_short(   // <= 24 residues: 4 waves per SIMD (128 VGPRs); the ordered mode FIVE (96 VGPRs; PFX: 30 KB of LDS) since its table offsets are packed (round 4b; the direct sweep: 422 ms that way, 404 at four)
     const uint8_t *__restrict__ codes, const int64_t *__restrict__ offsets, int64_t n,
     ScoreTable table, int32_t go, int32_t ge, int64_t row_begin, int64_t row_end, int symmetric,
     int kind, void *__restrict__ out_v, int64_t ld, int32_t *__restrict__ score_out,
@@ -218,7 +235,11 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
   __shared__ uint32_t mirror_res[ORD ? 1 : K3_THREADS / 64][ORD ? 1 : K3_ROWS_PER_WAVE][64];   // (ordered mode never mirrors)
   // PFX: a lane's checkpoint lives in LDS, [word][thread]: NMAX words of VM + NMAX / 2 words of Ix' scores packed two by two (the rest of an
   // XP word is priority 1 + the payload of the same column's VM) -- 30 KB at NMAX = 20, four workgroups per CU, no extra VGPRs
-  __shared__ uint32_t cp_lds[PFX ? NMAX + NMAX / 2 : 1][PFX ? K3_THREADS : 1];
+  // round 4b: the Ix' part as BYTES: d = score(VM[c]) - score(XP[c]) is >= 0 (VM is the max of three that include Ix') and only matters up to `go` --
+  // the next row takes max(VM[c] + kx, XP[c]) with score(VM[c] + kx) = score(VM[c]) - go, same priority, same payload: at d >= go the first operand wins or
+  // ties bit for bit -- so min(d, go) <= 255 is stored, four columns per word: 25 words = 25.6 KB at NMAX = 20, FIVE workgroups per CU
+  static_assert(!PFX || NMAX % 4 == 0, "the checkpoint packs four columns per word");
+  __shared__ uint32_t cp_lds[PFX ? NMAX + NMAX / 4 : 1][PFX ? K3_THREADS : 1];
 
   // ---- tile decode (upper-triangular 64x64 tiles of the pair space)
   const int64_t L = blockIdx.x;
@@ -322,6 +343,10 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
 #pragma unroll
     for (int c = 0; c < NMAX; ++c)
       boff[c] = (c < nj ? (uint32_t)codes[b + c] : 0u) * (uint32_t)(CK ? sizeof(int32_t) : sizeof(Cell));
+    if (CK && ORD && NMAX <= 24) {                       // (ordered mode: four offsets per register, see nw_row_ck<.., PACKB>)
+#pragma unroll
+      for (int c = 0; c < NMAX; c += 4) boff[c >> 2] = boff[c] | (boff[c + 1] << 8) | (boff[c + 2] << 16) | (boff[c + 3] << 24);
+    }
   }
   __syncthreads();
 
@@ -338,12 +363,16 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
     for (int rr = 0; rr < K3_ROWS_PER_WAVE; ++rr) my_res[rr * 64] = 0xffffffffu;  // = nothing to mirror
   }
 
+  // (values read from LDS / derived from the wave id are wave-uniform, but the compiler cannot know: through v_readfirstlane they -- and the loop
+  //  counters and addresses computed from them -- stay in SGPRs: without it the PFX kernel kept the row loop's counter, limit and residue address in
+  //  VGPRs, ran the loop under an exec mask and, at five waves per SIMD, spilled the address inside the row loop)
+  auto uni = [](int x) -> int { return __builtin_amdgcn_readfirstlane(x); };
   // PFX: the checkpoint (state of a row computed earlier in this wave's group at depth cp_depth) and the smallest common prefix met since
   int cp_depth = 0, since_min = 255, pfx_start = 0, pfx_save = 0;
   // the rows a wave takes: 16 consecutive ones -- or, PFX, a quarter of the tile's NEEDED rows by estimated cost, consecutive in sorted order, so that the four
   // waves of a workgroup finish together (with fixed groups of 16 -- or equal counts -- a workgroup kept its slot for its slowest wave:
   // 25 % fewer instructions gave 8 % less time)
-  int it_begin = wave * K3_ROWS_PER_WAVE, it_end = it_begin + K3_ROWS_PER_WAVE;
+  int it_begin = uni(wave) * K3_ROWS_PER_WAVE, it_end = it_begin + K3_ROWS_PER_WAVE;
   if (PFX) {
     // estimated DP rows of every needed row: its length minus what it shares with the previous needed row; a wave takes the consecutive
     // needed rows whose running cost falls into its quarter
@@ -353,28 +382,28 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
       int mn = 255;
       bool have_prev = false;
       for (int r = 0; r < K3_TILE; ++r) {
-        mn = min(mn, (int)rowlcp[r]);
+        mn = min(mn, uni((int)rowlcp[r]));
         if ((need_mask >> r) & 1ull) {
-          total += max(1, rowlen[r] - (have_prev ? mn : 0)) + 1;
+          total += max(1, uni(rowlen[r]) - (have_prev ? mn : 0)) + 1;
           mn = 255;
           have_prev = true;
         }
       }
     }
     const int waves = K3_THREADS / 64;
-    const int lo = wave * total / waves, hi = (wave + 1) * total / waves;   // this wave: rows whose running cost starts in [lo, hi)
+    const int lo = uni(wave) * total / waves, hi = (uni(wave) + 1) * total / waves;   // this wave: rows whose running cost starts in [lo, hi)
     it_begin = it_end = 0;
     {
       int mn = 255, run = 0;
       bool have_prev = false, any = false;
       for (int r = 0; r < K3_TILE; ++r) {
-        mn = min(mn, (int)rowlcp[r]);
+        mn = min(mn, uni((int)rowlcp[r]));
         if ((need_mask >> r) & 1ull) {
           if (run >= lo && run < hi) {
             if (!any) { it_begin = r; any = true; }
             it_end = r + 1;
           }
-          run += max(1, rowlen[r] - (have_prev ? mn : 0)) + 1;
+          run += max(1, uni(rowlen[r]) - (have_prev ? mn : 0)) + 1;
           mn = 255;
           have_prev = true;
         }
@@ -386,17 +415,17 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
     int64_t i = I0 + lr;
     if (i >= n) break;
     if (PFX) {
-      since_min = min(since_min, (int)rowlcp[lr]);
-      if (!rowneed[lr]) continue;
-      i = rowid[lr];
+      since_min = min(since_min, uni((int)rowlcp[lr]));
+      if (!uni((int)rowneed[lr])) continue;
+      i = uni(rowid[lr]);
       pfx_start = (cp_depth > 0 && cp_depth <= since_min) ? cp_depth : 0;
       // the depth the NEXT needed row of this wave shares with this one: checkpoint there, if that row is computed now
       pfx_save = 0;
       {
         int mn = 255;
         for (int l2 = lr + 1; l2 < it_end; ++l2) {
-          mn = min(mn, (int)rowlcp[l2]);
-          if (rowneed[l2]) { pfx_save = mn; break; }
+          mn = min(mn, uni((int)rowlcp[l2]));
+          if (uni((int)rowneed[l2])) { pfx_save = mn; break; }
         }
       }
       if (pfx_save <= pfx_start) pfx_save = 0;
@@ -406,7 +435,7 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
     const bool want_direct = allow_direct && i >= row_begin && i < row_end;
     const bool want_mirror_any = allow_mirror && J0 < row_end && J0 + 63 >= row_begin;
     if (!want_direct && !want_mirror_any) continue;
-    const int32_t m = rowlen[lr];
+    const int32_t m = PFX ? uni(rowlen[lr]) : rowlen[lr];
 
     uint32_t mt, ln;
     int32_t sc;
@@ -480,13 +509,22 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
 #pragma unroll
         for (int c = 0; c < NMAX; ++c) VM[c] = (int32_t)cp_lds[c][threadIdx.x];
 #pragma unroll
-        for (int c = 0; c < NMAX; c += 2) {
-          const uint32_t pk = cp_lds[NMAX + c / 2][threadIdx.x];
-          XP[c] = (int32_t)((uint32_t)((int32_t)(int16_t)(pk & 0xffffu)) << CK_S2) | (1 << CK_S) | (VM[c] & ((1 << CK_S) - 1));
-          XP[c + 1] = (int32_t)((uint32_t)((int32_t)pk >> 16) << CK_S2) | (1 << CK_S) | (VM[c + 1] & ((1 << CK_S) - 1));
+        for (int c = 0; c < NMAX; c += 4) {
+          const uint32_t pk = cp_lds[NMAX + c / 4][threadIdx.x];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int32_t d = (int32_t)((pk >> (8 * q)) & 0xffu);
+            XP[c + q] = (int32_t)((uint32_t)((VM[c + q] >> CK_S2) - d) << CK_S2) | (1 << CK_S) | (VM[c + q] & ((1 << CK_S) - 1));
+          }
         }
       }
-      for (int32_t r = (PFX ? pfx_start : 0) + 1; r <= m; ++r) {
+      // the DP rows (r_from, r_to]; PFX runs them in two pieces with the checkpoint in between -- kept OUT of the row loop: with the save block inside it the
+      // loop did not fit the 96 VGPRs of five waves per SIMD (three scratch reloads per DP row)
+      const int32_t r_cut = (PFX && pfx_save > 0) ? pfx_save : m;      // PFX: rows (pfx_start, pfx_save], checkpoint, rows (pfx_save, m] -- ONE copy of the row loop
+#pragma nounroll
+      for (int piece = 0; piece < (PFX ? 2 : 1); ++piece) {
+      const int32_t r_from = piece == 0 ? (PFX ? pfx_start : 0) : r_cut, r_to = piece == 0 ? r_cut : m;
+      for (int32_t r = r_from + 1; r <= r_to; ++r) {
         // (making this offset opaque to the compiler turns the per-cell v_mad into a v_add but lets it
         // hoist all 20 lookups: 141 VGPRs / 3 waves per SIMD and 15 % slower -- measured, not kept)
         uint32_t row_off;
@@ -504,15 +542,20 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? 4 : 1)) void k_nw_short( 
         const int32_t vm_diag0 = (r == 1) ? 0 : ((ge - go) << CK_S2);
         const int32_t left0 = CK_NEG << CK_S2;
         if (r == 1)
-          nw_row_ck<NMAX, true>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
+          nw_row_ck<NMAX, true, (ORD && NMAX <= 24)>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
         else
-          nw_row_ck<NMAX, false>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
-        if (PFX && r == pfx_save) {                                  // the next needed row of the group shares this many rows: checkpoint
+          nw_row_ck<NMAX, false, (ORD && NMAX <= 24)>(VM, XP, boff, tab_row, vm_diag0, left0, left0, kx, ky, ixf_first, pay_mask, pri_clear);
+      }
+        if (PFX && piece == 0 && pfx_save > 0) {                     // the next needed row of the group shares this many rows: checkpoint
 #pragma unroll
           for (int c = 0; c < NMAX; ++c) cp_lds[c][threadIdx.x] = (uint32_t)VM[c];
 #pragma unroll
-          for (int c = 0; c < NMAX; c += 2)                          // Ix' scores fit 16 bits (sentinel -24000 - gaps > -32768: CKBits' penalty limit)
-            cp_lds[NMAX + c / 2][threadIdx.x] = ((uint32_t)(XP[c] >> CK_S2) & 0xffffu) | ((uint32_t)(XP[c + 1] >> CK_S2) << 16);
+          for (int c = 0; c < NMAX; c += 4) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pk |= (uint32_t)min((VM[c + q] >> CK_S2) - (XP[c + q] >> CK_S2), go) << (8 * q);   // (go <= 255: the launcher's condition)
+            cp_lds[NMAX + c / 4][threadIdx.x] = pk;
+          }
         }
       }
       if (PFX && pfx_save > 0) { cp_depth = pfx_save; since_min = 255; }
@@ -1386,7 +1429,7 @@ int launch_nw(const uint8_t *d_codes, const int64_t *d_off, int64_t n, int64_t m
 #define DA_K3_ARGS d_codes, d_off, n, st, (int32_t)gap_open, (int32_t)gap_ext, row_begin, row_end, symmetric ? 1 : 0, kind, d_out, ld, \
                    d_score, ld_score, ntiles, T, shard_rank, shard_world, fold_q, fold_w, ord_first, ord_minfirst, ord_maxlast, ord_perm, ord_lcp
   // ordered mode on the whole table with the rows' sorted order given (launch_nw_sort_unique): prefix sharing (k_nw_short<.., PFX>)
-  const bool pfx = ord_first && ord_perm && ord_lcp && ck && shard_world == 0 && row_begin == 0 && row_end == n && max_len <= 20;   // (NMAX = 24: 135 VGPRs, three waves)
+  const bool pfx = ord_first && ord_perm && ord_lcp && ck && shard_world == 0 && row_begin == 0 && row_end == n && max_len <= 20 && gap_open <= 255;   // (NMAX = 24: 135 VGPRs, three waves; gap_open: the checkpoint's byte deltas)
 #ifdef DA_K2_EXPERIMENTS
   const bool asm_rows = ck && getenv("DYNAALIGN_NW_ASM");     // experiment library only: the generated rows (tools/gen_nw_asm.py)
 #else

@@ -119,10 +119,16 @@ def nw_disassembly(tmp_path_factory):
                            "--cuda-device-only", "-S", os.path.join(CSRC, "nw_kernels.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
     text = open(out).read()
     kernels = {}
-    for m in re.finditer(r"^(_ZN2da12_GLOBAL__N_110k_nw_shortILi(\d+)ELb([01])ELb([01])ELb([01])E\w+):.*?^\.Lfunc_end\d+:", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN2da12_GLOBAL__N_110k_nw_shortILi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])E\w+):.*?^\.Lfunc_end\d+:", text, re.S | re.M):
+        if m.group(6) == "1":
+            continue                                                          # (the prefix-sharing instances of the ordered mode: see the test below)
         kernels[(int(m.group(2)), m.group(3) == "1", m.group(4) == "1", m.group(5) == "1")] = (m.group(1), m.group(0))
+    pfx = {}
+    for m in re.finditer(r"^(_ZN2da12_GLOBAL__N_110k_nw_shortILi(\d+)ELb1ELb1ELb0ELb1E\w+):.*?^\.Lfunc_end\d+:", text, re.S | re.M):
+        pfx[int(m.group(2))] = (m.group(1), m.group(0))
+    kernels["pfx"] = pfx
     meta = {}
-    for (key, (name, _)) in kernels.items():
+    for (key, (name, _)) in [kv for kv in kernels.items() if kv[0] != "pfx"] + [(("pfx", n_), v_) for n_, v_ in pfx.items()]:
         meta[key] = {k: int(re.search(r"\.set %s\.%s, (\d+)" % (re.escape(name), k), text).group(1)) for k in ("num_vgpr", "private_seg_size")}
     return kernels, meta
 
@@ -133,7 +139,10 @@ def test_direct_sweeps_row_ahead_read_owns_its_register(nw_disassembly):
     before the wait)"""
     kernels, meta = nw_disassembly
     checked = 0
-    for (nmax, ck, ordered, asm), (name, body) in kernels.items():
+    for key, val in kernels.items():
+        if key == "pfx":
+            continue
+        (nmax, ck, ordered, asm), (name, body) = key, val
         if not ck or ordered or asm or nmax > 24:
             continue
         lines = body.split("\n")
@@ -153,8 +162,47 @@ def test_direct_sweeps_row_ahead_read_owns_its_register(nw_disassembly):
 
 def test_generated_row_kernels_use_no_scratch_and_fit_four_waves(nw_disassembly):
     kernels, meta = nw_disassembly
-    asm_kernels = [k for k in kernels if k[3]]
+    asm_kernels = [k for k in kernels if k != "pfx" and k[3]]
     assert sorted(set(k[0] for k in asm_kernels)) == [12, 20] and all(k[1] for k in asm_kernels)       # combined key; ordered mode and direct sweep
     for k in asm_kernels:
         assert meta[k]["num_vgpr"] <= 128 and (meta[k]["private_seg_size"] == 0 or not k[2]), (k, meta[k])   # (the direct sweep spills 8 bytes around the block)
         assert sum("v_max3_i32" in l for l in kernels[k][1].split("\n")) >= 4 * k[0]
+
+
+def _row_loop(body):
+    """the innermost loop of a k_nw_short instance that holds one DP row (NMAX v_max3_i32): (first line, last line) of the disassembly"""
+    lines = body.split("\n")
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    best = None
+    for i, l in enumerate(lines):
+        m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            a, b = labels[m.group(1)], i
+            if sum("v_max3_i32" in x for x in lines[a:b]) >= 8 and (best is None or b - a < best[1] - best[0]):
+                best = (a, b)
+    return lines, best
+
+
+def test_ordered_kernels_fit_five_waves_without_spills_in_the_row_loop(nw_disassembly):
+    """round 4b: the ordered mode (plain and prefix-sharing) runs five waves per SIMD -- 96 VGPRs: sequence2's table offsets four to a register (SDWA byte
+    select in the address add), wave-uniform loop state in SGPRs, the checkpoint's Ix' part as byte deltas (25 words: 30 KB of LDS per workgroup).  What may
+    not happen again: a scratch access inside the DP row loop (the first five-wave build reloaded the residue address every row: 92.5 ms instead of 82.5)"""
+    kernels, meta = nw_disassembly
+    checked = 0
+    for nmax, (name, body) in sorted(kernels["pfx"].items()):
+        vg = meta[("pfx", nmax)]["num_vgpr"]
+        assert vg <= 96, (name, vg)
+        lines, loop = _row_loop(body)
+        assert loop is not None, name
+        assert not any("scratch_" in l for l in lines[loop[0]:loop[1] + 1]), name
+        assert sum("v_add_u32_sdwa" in l for l in lines[loop[0]:loop[1] + 1]) >= nmax, name        # the packed offsets are unpacked inside the loop, not hoisted
+        checked += 1
+    assert checked >= 4                                                                            # NMAX 8, 12, 16, 20
+    for (key, val) in kernels.items():
+        if key == "pfx":
+            continue
+        (nmax, ck, ordered, asm), (name, body) = key, val
+        if ck and ordered and not asm and nmax <= 24:
+            assert meta[key]["num_vgpr"] <= 96, (name, meta[key])
+            lines, loop = _row_loop(body)
+            assert loop is not None and not any("scratch_" in l for l in lines[loop[0]:loop[1] + 1]), name
