@@ -435,7 +435,7 @@ __global__ __launch_bounds__(K3_THREADS, (NMAX <= 24 ? (CK && ORD && !ASM ? 5 : 
     const bool want_direct = allow_direct && i >= row_begin && i < row_end;
     const bool want_mirror_any = allow_mirror && J0 < row_end && J0 + 63 >= row_begin;
     if (!want_direct && !want_mirror_any) continue;
-    const int32_t m = PFX ? uni(rowlen[lr]) : rowlen[lr];
+    const int32_t m = uni(rowlen[lr]);
 
     uint32_t mt, ln;
     int32_t sc;
