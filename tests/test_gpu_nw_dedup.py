@@ -162,3 +162,9 @@ def test_prefix_sharing_of_the_ordered_dp(da, small_n_route, monkeypatch, seed, 
     assert same(plain, want)
     got2, _ = both_routes(da, seqs, "BLOSUM45", 3, 1)               # other penalties: more gaps, other tie-breaks
     assert same(got2, oracle_matrix(seqs, "BLOSUM45", 3, 1))
+    if seed == 2:
+        # the checkpoint keeps Ix' as byte deltas min(score(VM) - score(Ix'), gapOpen): no gap-open cost at all (every delta clamps to 0), the largest
+        # gapOpen the bytes hold, one past it (that call takes the plain ordered kernel), extension-only and open-only penalties
+        for go, ge in ((0, 0), (1, 0), (0, 3), (255, 2), (256, 2), (40, 20)):
+            got3 = np.asarray(da.similarityNW(seqs, "BLOSUM62", go, ge))
+            assert same(got3, oracle_matrix(seqs, "BLOSUM62", go, ge)), (go, ge)
