@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-/* 2: the folded shard layout changed (da_shard_ld = ceil8(n) + world * 128, back-aligned rows start at column world * 128) and the
+/* (round 4 added entry points only -- da_config_reload, da_debug_comm_cache_state, da_mh_last_route_split: the version stays)
+ * 2: the folded shard layout changed (da_shard_ld = ceil8(n) + world * 128, back-aligned rows start at column world * 128) and the
  *    duplicate-route / multi-device entry points were added; every round-1 entry point keeps its signature */
 #define DA_ABI_VERSION 2
 
