@@ -130,23 +130,24 @@ def test_split_really_moves_incidences_to_the_lists(da):
     assert route["split"] and route["rare_pairs"] == rare and rare > 0
 
 
-@pytest.mark.parametrize("case", ["odd_ld", "n_hash_600", "n_hash_40", "n_hash_33"])
-def test_split_shapes_the_hand_scheduled_kernel_does_not_take(da, case):
-    """odd leading dimension / n_hash beyond the float64 table of the 8-plane kernel: every tile through the compiled 8-plane kernel, then the same fix-up"""
+@pytest.mark.parametrize("case", ["odd_ld", "even_padded_ld", "n_hash_600", "n_hash_2047", "n_hash_40", "n_hash_33"])
+def test_split_shapes_at_the_edges_of_the_hand_scheduled_kernel(da, case):
+    """odd leading dimension: every tile through the compiled 8-plane kernel, then the same fix-up; a padded even one, the largest n_hash the 8-plane kernel's
+    float64 table holds (2047), the smallest with two stages (33): the hand-scheduled kernel"""
     import torch
     rng = np.random.RandomState(11)
     seqs = clustered(rng, 3000)
     n = len(seqs)
-    n_hash = {"odd_ld": 500, "n_hash_600": 600, "n_hash_40": 40, "n_hash_33": 33}[case]
+    n_hash = {"odd_ld": 500, "even_padded_ld": 500, "n_hash_600": 600, "n_hash_2047": 2047, "n_hash_40": 40, "n_hash_33": 33}[case]
     out = None
-    if case == "odd_ld":
-        buf = torch.full((n, n + 1), -1.0, dtype=torch.float64, device="cuda")
+    if case in ("odd_ld", "even_padded_ld"):
+        buf = torch.full((n, n + (1 if case == "odd_ld" else 6)), -1.0, dtype=torch.float64, device="cuda")
         out = buf[:, :n]
     got, route = run(seqs, 4, n_hash, out=out, **SPLIT)
     assert route["split"], route
     assert same(got.cpu().numpy(), oracle(seqs, 4, n_hash))
-    if case == "odd_ld":
-        assert bool((buf[:, n] == -1.0).all())
+    if case in ("odd_ld", "even_padded_ld"):
+        assert bool((buf[:, n:] == -1.0).all())
 
 
 def test_split_is_not_asked_for_where_it_cannot_pay(da):
